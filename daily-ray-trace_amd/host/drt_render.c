@@ -1,0 +1,158 @@
+/*
+ * drt_render.c -- render_image() for the POSIX + HIP host (replaces src/daily_ray_trace.c:635-777).
+ *
+ * Same inputs (config_arguments) and outputs (three .spd files) as the reference. The
+ * `for sample / for y / for x` loop (src/daily_ray_trace.c:710-745) is ONE call into the
+ * C-ABI launcher (drt_render_tile, include/drt_hip.h); everything around it stays plain C.
+ * There is no CPU fallback: if the launcher fails, render_image reports it and exits.
+ */
+#include "drt_host.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+static f64 now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (f64)ts.tv_sec * 1000.0 + (f64)ts.tv_nsec * 1e-6;
+}
+
+/* 40-byte header + row-major pixels, y = 0 first (src/daily_ray_trace.c:667-680, :758-770) */
+int drt_host_write_spd(const char *path, u32 width, u32 height, u32 num_wl, u32 has_filter, f64 min_wl, f64 interval,
+                       const f64 *pixels)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    spd_file_header header;
+    memset(&header, 0, sizeof(header));
+    header.id = 0xedfeefbe;
+    header.width_in_pixels = width;
+    header.height_in_pixels = height;
+    header.number_of_wavelengths = num_wl;
+    header.has_filter_values = has_filter;
+    header.min_wavelength = min_wl;
+    header.wavelength_interval = interval;
+    size_t per_pixel = (size_t)num_wl + (has_filter ? 1 : 0);
+    size_t count = (size_t)width * height * per_pixel;
+    int ok = fwrite(&header, sizeof(header), 1, f) == 1 && fwrite(pixels, sizeof(f64), count, f) == count;
+    fclose(f);
+    return ok ? 0 : -1;
+}
+
+int drt_host_read_spd(const char *path, spd_file_header *header, f64 **pixels)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return -1;
+    if (fread(header, sizeof(*header), 1, f) != 1 || header->id != 0xedfeefbe) { fclose(f); return -2; }
+    size_t per_pixel = (size_t)header->number_of_wavelengths + (header->has_filter_values ? 1 : 0);
+    size_t count = (size_t)header->width_in_pixels * header->height_in_pixels * per_pixel;
+    *pixels = (f64 *)malloc(count * sizeof(f64));
+    if (fread(*pixels, sizeof(f64), count, f) != count) { fclose(f); free(*pixels); *pixels = NULL; return -3; }
+    fclose(f);
+    return 0;
+}
+
+int render_image_ex(config_arguments *config, const drt_host_options *opt, drt_stats *stats_out)
+{
+    u32 width = config->output_width, height = config->output_height;
+    spd_tables_csvs csvs;
+    csvs.white = config->white_spd;  csvs.cmf_x = config->cmf_x;      csvs.cmf_y = config->cmf_y;
+    csvs.cmf_z = config->cmf_z;      csvs.rgb_red = config->red_spd;  csvs.rgb_green = config->green_spd;
+    csvs.rgb_blue = config->blue_spd; csvs.rgb_cyan = config->cyan_spd; csvs.rgb_magenta = config->magenta_spd;
+    csvs.rgb_yellow = config->yellow_spd;
+
+    /* material `csv` entries live next to the table CSVs (the reference hard-codes "spectra\") */
+    char spectra_dir[128];
+    snprintf(spectra_dir, sizeof(spectra_dir), "%s", config->white_spd);
+    char *slash = strrchr(spectra_dir, '/');
+    if (slash) *slash = 0; else snprintf(spectra_dir, sizeof(spectra_dir), "spectra");
+
+    drt_host_scene *hs = drt_host_load_scene(config->input_scene, spectra_dir, &csvs, width, height,
+                                             config->min_wl, config->max_wl, config->wl_interval);
+    if (!hs)
+    {
+        fprintf(stderr, "render_image: %s\n", drt_host_last_error());
+        return -1;
+    }
+    const drt_scene *scene = drt_host_scene_data(hs);
+    u32 S = scene->num_wavelengths;
+    u64 num_pixels = (u64)width * height;
+
+    /* zero-filled accumulators (VirtualAlloc semantics, src/daily_ray_trace.c:689-691), 64-bit sizes */
+    f64 *dst_pixels = (f64 *)calloc(num_pixels * (S + 1), sizeof(f64));
+    f64 *dst_avgs = (f64 *)calloc(num_pixels * S, sizeof(f64));
+    f64 *dst_vars = (f64 *)calloc(num_pixels * S, sizeof(f64));
+    if (!dst_pixels || !dst_avgs || !dst_vars)
+    {
+        fprintf(stderr, "render_image: out of memory for %llu pixels\n", (unsigned long long)num_pixels);
+        return -1;
+    }
+
+    drt_params p;
+    memset(&p, 0, sizeof(p));
+    p.width = width;
+    p.height = height;
+    p.tile_w = width;
+    p.tile_h = height;
+    p.row_stride = 1;
+    p.spp = config->num_pixel_samples;
+    p.max_depth = config->max_cast_depth;
+    p.pixel_scheme = (u32)config->pixel_scheme;
+    p.seed = opt ? opt->seed : 1;
+    p.mode = DRT_MODE_SPECTRAL;
+    p.device = opt ? opt->device : 0;
+    p.batch_spp = opt ? opt->batch_spp : 0;
+
+    drt_stats stats;
+    memset(&stats, 0, sizeof(stats));
+    f64 t0 = now_ms();
+    int rc = drt_render_tile(scene, drt_host_camera_data(hs), &p, dst_pixels, dst_avgs, dst_vars, &stats);
+    f64 t1 = now_ms();
+    if (rc != 0)
+    {
+        fprintf(stderr, "render_image: drt_render_tile failed (%d): %s\n", rc, drt_last_error());
+        return rc;
+    }
+    if (!(opt && opt->quiet))
+    {
+        printf("Total render time: %fms (device %fms: trace %fms, shade+film %fms)\n", t1 - t0, stats.total_ms,
+               stats.trace_ms, stats.shade_ms);
+        printf("Paths: %llu  closest-hit scans/path: %.3f  shaded vertices/path: %.3f  Mpaths/s (device): %.2f\n",
+               (unsigned long long)stats.paths, (f64)stats.closest_hit_scans / (f64)stats.paths,
+               (f64)stats.shaded_vertices / (f64)stats.paths, (f64)stats.paths / (stats.total_ms * 1e3));
+    }
+
+    /* variance is max-normalised per pixel before writing (src/daily_ray_trace.c:766-769) */
+    for (u64 px = 0; px < num_pixels; px += 1)
+    {
+        f64 *v = dst_vars + px * S;
+        f64 highest = 0.0;
+        for (u32 i = 0; i < S; i += 1) if (v[i] > highest) highest = v[i];
+        for (u32 i = 0; i < S; i += 1) v[i] /= highest;
+    }
+    int w0 = drt_host_write_spd(config->output_spd, width, height, S, 1, scene->min_wavelength, scene->wavelength_interval, dst_pixels);
+    int w1 = drt_host_write_spd(config->variance_spd, width, height, S, 0, scene->min_wavelength, scene->wavelength_interval, dst_vars);
+    int w2 = drt_host_write_spd(config->average_spd, width, height, S, 0, scene->min_wavelength, scene->wavelength_interval, dst_avgs);
+    if (w0 || w1 || w2) fprintf(stderr, "render_image: could not write one of the .spd outputs\n");
+    if (stats_out) *stats_out = stats;
+    free(dst_vars);
+    free(dst_avgs);
+    free(dst_pixels);
+    drt_host_free_scene(hs);
+    return (w0 || w1 || w2) ? -2 : 0;
+}
+
+void render_image(config_arguments *config)
+{
+    drt_host_options opt;
+    memset(&opt, 0, sizeof(opt));
+    const char *e;
+    opt.seed = 1;
+    if ((e = getenv("DRT_DEVICE"))) opt.device = atoi(e);
+    if ((e = getenv("DRT_SEED"))) opt.seed = strtoull(e, NULL, 0);
+    if ((e = getenv("DRT_BATCH_SPP"))) opt.batch_spp = (u32)atoi(e);
+    if (render_image_ex(config, &opt, NULL) != 0) exit(-1);
+}

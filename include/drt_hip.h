@@ -1,0 +1,233 @@
+/*
+ * drt_hip.h -- C-ABI of the MI355X render launcher (libdrt_hip.so).
+ *
+ * This is the drop-in boundary for the per-pixel render loop of daily-ray-trace:
+ * the host (plain C, POSIX) keeps loading .scn scenes and spectra CSVs exactly as
+ * before, flattens them into the plain structs below, and calls drt_render_tile()
+ * (or the drt_create/drt_render/drt_read_film session form) where the reference
+ * runs its `for sample / for y / for x` loop.
+ *
+ * Reference interfaces replaced (paths relative to the reference tree):
+ *   - the pixel loop of render_image()           src/daily_ray_trace.c:710-745
+ *   - sample_scene()                             src/daily_ray_trace.c:571-618
+ *   - cast_ray() and everything below it         src/daily_ray_trace.c:215-479
+ *   - the BDSF / direction-sampling plugin tables src/bdsf.h:1-52, src/bdsf_list.h
+ *   - rng()/seed_rng()                           src/rng.h:1-2
+ *   - spectrum_to_xyz()                          src/spectrum.c:49-70
+ *
+ * Everything here is plain C: pointers, sizes, doubles. No C++ or torch types.
+ * All arithmetic on the path is IEEE f64; integers are u32/u64.
+ *
+ * The oracle (oracle/drt_oracle.h) consumes the SAME structs, so a parity test
+ * hands one scene to both sides.
+ */
+#ifndef DRT_HIP_H
+#define DRT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRT_MAX_BDSFS 16 /* object_material.bdsfs[16], src/daily_ray_trace.h:109 */
+
+/* Surface kinds keep the reference's numeric values (src/daily_ray_trace.h:7-14). */
+enum
+{
+    DRT_GEO_NONE   = 0,
+    DRT_GEO_POINT  = 1,
+    DRT_GEO_SPHERE = 2,
+    DRT_GEO_PLANE  = 3
+};
+
+/* film_sample_scheme, src/daily_ray_trace.h:20-26 */
+enum
+{
+    DRT_FILM_SAMPLE_CENTER = 1,
+    DRT_FILM_SAMPLE_RANDOM = 2
+};
+
+/*
+ * Material plugin IDs. The names and their ORDER come from bdsf_list.h (the same
+ * X-macro file the reference expands into function-pointer tables); here the list
+ * expands to integer IDs because function pointers do not cross to the GPU.
+ */
+#define BDSF(name) DRT_BDSF_##name,
+#define DIRF(name)
+enum
+{
+#include "bdsf_list.h"
+    DRT_NUM_BDSFS
+};
+#undef BDSF
+#undef DIRF
+#define BDSF(name)
+#define DIRF(name) DRT_DIRF_##name,
+enum
+{
+#include "bdsf_list.h"
+    DRT_NUM_DIRFS
+};
+#undef BDSF
+#undef DIRF
+
+/* One surface: object_geometry (src/daily_ray_trace.h:78-93) without the name.
+ * Planes carry the derived normal/u/v of create_plane_from_points (src/geometry.c:203-209). */
+typedef struct drt_surface
+{
+    uint32_t type;     /* DRT_GEO_* */
+    uint32_t material; /* index into drt_scene.materials */
+    double   position[3];
+    double   radius;   /* spheres */
+    double   normal[3];
+    double   u[3];
+    double   v[3];
+} drt_surface;
+
+/* One material: object_material (src/daily_ray_trace.h:95-111). SPDs are indices into
+ * drt_scene.spds; -1 means "not given" (a NULL spectrum in the reference) and reads as zeros. */
+typedef struct drt_material
+{
+    uint32_t is_black_body;
+    uint32_t is_emissive;
+    double   shininess;
+    double   roughness;
+    int32_t  emission_spd;
+    int32_t  diffuse_spd;
+    int32_t  glossy_spd;
+    int32_t  mirror_spd;
+    int32_t  refract_spd;
+    int32_t  extinct_spd;
+    uint32_t num_bdsfs;
+    uint32_t bdsfs[DRT_MAX_BDSFS]; /* DRT_BDSF_* */
+    uint32_t dir_func;             /* DRT_DIRF_* */
+} drt_material;
+
+/* scene_data (src/daily_ray_trace.h:146-156) plus the spectral tables the path reads. */
+typedef struct drt_scene
+{
+    uint32_t           num_surfaces;
+    const drt_surface *surfaces;
+    uint32_t           num_materials;
+    const drt_material *materials;
+    uint32_t           base_material;   /* scene_data.base_material   */
+    uint32_t           escape_material; /* scene_data.escape_material */
+
+    uint32_t      num_spds;
+    uint32_t      num_wavelengths; /* number_of_spectrum_samples, src/spectrum.h:3 */
+    const double *spds;            /* [num_spds][num_wavelengths] */
+    double        min_wavelength;  /* smallest_wavelength (nm)     */
+    double        wavelength_interval;
+    /* colour-matching tables (cmfs, src/spectrum.h:17-23) as SPD indices */
+    uint32_t cmf_rw, cmf_x, cmf_y, cmf_z;
+} drt_scene;
+
+/* camera_data, src/daily_ray_trace.h:158-170 -- same fields, same meaning. */
+typedef struct drt_camera
+{
+    double forward[3];
+    double right[3];
+    double up[3];
+    double aperture_position[3];
+    double aperture_radius;
+    double focal_depth;
+    double focal_length;
+    double film_bottom_left[3];
+    double pixel_width;
+    double pixel_height;
+} drt_camera;
+
+enum
+{
+    DRT_MODE_SPECTRAL = 0, /* film = sum(+filter), mean, variance per wavelength (the reference's output) */
+    DRT_MODE_XYZ      = 1  /* additionally keep only XYZ; reported as a different mode */
+};
+
+/*
+ * What to render. The tile is the pixel set {(x0+i, y0+j*row_stride) : i<tile_w, j<tile_h} of a
+ * width x height image (row_stride>1 gives the row-cyclic multi-GPU partition). Path RNG key
+ * (SURVEY 8a-R): seed + ((sample*height + y)*width + x) as u64, xorshift64 seeded through splitmix64.
+ */
+typedef struct drt_params
+{
+    uint32_t width, height;
+    uint32_t x0, y0, tile_w, tile_h, row_stride;
+    uint32_t spp;          /* num_pixel_samples  */
+    uint32_t first_sample; /* index of the first sample (resume support) */
+    uint32_t max_depth;    /* max_cast_depth     */
+    uint32_t pixel_scheme; /* DRT_FILM_SAMPLE_*  */
+    uint64_t seed;
+    uint32_t mode;         /* DRT_MODE_* */
+    int32_t  device;       /* HIP device ordinal */
+    uint32_t batch_spp;    /* samples traced per launch pair (0 = library default) */
+    uint32_t flags;        /* DRT_FLAG_* */
+} drt_params;
+
+enum
+{
+    DRT_FLAG_RECORD_HITS = 1u /* keep closest-hit surface indices per path vertex (parity tests) */
+};
+
+typedef struct drt_stats
+{
+    uint64_t paths;
+    uint64_t closest_hit_scans; /* find_ray_intersection calls (V_int)       */
+    uint64_t shaded_vertices;   /* direct_light_contribution calls (V_shade) */
+    uint64_t shadow_scans;      /* points_mutually_visible calls             */
+    uint64_t rng_draws;
+    double   trace_ms;          /* path-geometry kernel, HIP-event time      */
+    double   shade_ms;          /* spectral shade + film kernel              */
+    double   total_ms;
+} drt_stats;
+
+typedef struct drt_context drt_context;
+
+/* Last error text of the calling thread ("" when none). */
+const char *drt_last_error(void);
+/* Number of HIP devices visible; negative on error. */
+int drt_device_count(void);
+
+/* Session form. drt_create copies the scene to the device (SoA) and allocates the film
+ * (zero-filled, like the reference's VirtualAlloc'ed accumulators, src/daily_ray_trace.c:689-691). */
+drt_context *drt_create(const drt_scene *scene, const drt_camera *camera, const drt_params *params);
+void         drt_destroy(drt_context *ctx);
+/* Use caller-owned DEVICE buffers for the film instead of the library's own
+ * ([tile_h*tile_w][S+1], [..][S], [..][S] doubles). The caller zero-fills them. */
+int drt_bind_film(drt_context *ctx, void *d_pixels, void *d_avgs, void *d_vars);
+/* Launch on this hipStream_t (NULL = the context's own stream). */
+int drt_set_stream(drt_context *ctx, void *hip_stream);
+/* Enqueue samples [first_sample, first_sample+num_samples) for every tile pixel. Asynchronous. */
+int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_samples);
+int drt_synchronize(drt_context *ctx);
+/* Zero the film and the statistics (for repeated timed runs). */
+int drt_reset_film(drt_context *ctx);
+/* Device pointers of the film buffers (for collectives on them). */
+int drt_film_device_ptrs(drt_context *ctx, void **d_pixels, void **d_avgs, void **d_vars);
+/* Copy the film to host buffers (any may be NULL). Synchronises. */
+int drt_read_film(drt_context *ctx, double *pixels, double *avgs, double *vars);
+/* Per-pixel XYZ of sum/filter (spectrum_to_xyz on the device), [tile_h*tile_w][3]. Synchronises. */
+int drt_read_xyz(drt_context *ctx, double *xyz);
+/* Closest-hit surface indices of the LAST rendered sample batch: [n][max_depth] int32 per path
+ * (-1 miss, -2 vertex not reached); needs DRT_FLAG_RECORD_HITS. Paths are ordered
+ * (sample - first_sample_of_last_call, tile row, tile column). */
+int drt_read_hit_indices(drt_context *ctx, int32_t *dst, uint64_t capacity_paths);
+int drt_get_stats(drt_context *ctx, drt_stats *out);
+
+/*
+ * One-shot form matching the reference's loop: host buffers, caller-owned,
+ * accumulated INTO (so the caller zero-fills them, as alloc() does in the reference).
+ * Returns 0 on success, negative on failure (see drt_last_error()).
+ */
+int drt_render_tile(const drt_scene *scene, const drt_camera *camera, const drt_params *params,
+                    double *dst_pixels, double *dst_avgs, double *dst_vars, drt_stats *stats);
+
+/* Arithmetic self-test kernels: evaluate op over n inputs on the device so tests can check
+ * that f64 sqrt / divide / the path's sincos are bit-identical to the host. op: 0 sqrt(a),
+ * 1 a/b, 2 sincos(a) -> out[2*i], out[2*i+1], 3 pow(a,b), 4 rng stream from key a (as u64 bits). */
+int drt_selftest_arith(int device, int op, const double *a, const double *b, double *out, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRT_HIP_H */

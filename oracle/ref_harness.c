@@ -1,0 +1,457 @@
+/*
+ * ref_harness.c -- drives the REAL reference code of the render path, compiled from the
+ * reference's own source files where they lie (/root/reference/src). TEST INFRASTRUCTURE ONLY.
+ *
+ * This file contains no reference code. It is built by oracle/Makefile (target `ref`) into
+ * oracle/_ref/libdrt_ref.so, only in a container where /root/reference exists. The Makefile
+ * hands it two generated include files (kept in a temp dir, never committed, never shipped):
+ *   drt_ref_types.h  = src/daily_ray_trace.h minus the five #include lines that pull in the
+ *                      Win32 platform layer, the .scn parser and the render driver
+ *                      (<Windows.h>, win32_platform.h/.c, read_scene.c, daily_ray_trace.c);
+ *   drt_ref_path.inc = src/daily_ray_trace.c lines 49-77 (init_camera), 213-479 (bdsf ..
+ *                      cast_ray) and 545-618 (sample_pixel_point, sample_scene), verbatim.
+ * Every other reference file used (types.h utils.[ch] spectrum.[ch] geometry.[ch] rng.[ch]
+ * bdsf.[ch] bdsf_list.h read_scene.h) is included whole, unmodified, straight from the tree.
+ * No stand-in is written for any header, library or function the image lacks: the platform
+ * layer, the parser and render_image are simply not part of this build (their callers are
+ * dropped by --gc-sections), and scene data arrives through the boundary structs instead.
+ *
+ * rand()/srand() are macro-renamed to the build's per-path xorshift64;
+ * glibc's RAND_MAX (2^31-1) is what rng() divides by.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define REF_API __attribute__((visibility("default")))
+
+static uint64_t g_ref_rng_state = 1;
+static uint64_t g_ref_rng_draws = 0;
+static int drt_probe_rand(void)
+{
+    uint64_t x = g_ref_rng_state;
+    x ^= x << 13;
+    x ^= x >> 7;
+    x ^= x << 17;
+    g_ref_rng_state = x;
+    g_ref_rng_draws += 1;
+    return (int)(uint32_t)(x >> 33);
+}
+static void drt_probe_srand(unsigned seed) { g_ref_rng_state = seed ? seed : 1; }
+#define rand drt_probe_rand
+#define srand drt_probe_srand
+
+#include "drt_ref_types.h" /* generated: see header comment */
+#include "drt_ref_path.inc"
+
+#undef rand
+#undef srand
+
+#include "../include/drt_hip.h"
+
+/* ---- RNG ---------------------------------------------------------------------------------- */
+static uint64_t splitmix64(uint64_t k)
+{
+    uint64_t z = k + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z ? z : 1ull;
+}
+REF_API void ref_seed_path(uint64_t key) { g_ref_rng_state = splitmix64(key); }
+REF_API void ref_set_rng_state(uint64_t s) { g_ref_rng_state = s; }
+REF_API uint64_t ref_get_rng_state(void) { return g_ref_rng_state; }
+REF_API uint64_t ref_rng_draws(void) { return g_ref_rng_draws; }
+REF_API double ref_rng(void) { return rng(); }
+
+/* ---- spectral grid and tables (the reference's globals, filled from the boundary structs) ---- */
+static f64 *g_block = NULL;
+
+REF_API void ref_set_grid(uint32_t n, double min_wl, double interval)
+{
+    number_of_spectrum_samples = n;
+    smallest_wavelength = min_wl;
+    sample_interval = interval;
+    largest_wavelength = min_wl + (n - 1) * interval;
+    spectrum_size = n * sizeof(f64);
+    free(g_block);
+    uint32_t stack_capacity = 32; /* src/daily_ray_trace.c:658 */
+    g_block = (f64 *)calloc((size_t)(11 + stack_capacity) * n, sizeof(f64));
+    cmfs.rw.samples = g_block + 0 * n;
+    cmfs.x.samples = g_block + 1 * n;
+    cmfs.y.samples = g_block + 2 * n;
+    cmfs.z.samples = g_block + 3 * n;
+    rgb_spds.white.samples = g_block + 4 * n;
+    rgb_spds.red.samples = g_block + 5 * n;
+    rgb_spds.green.samples = g_block + 6 * n;
+    rgb_spds.blue.samples = g_block + 7 * n;
+    rgb_spds.cyan.samples = g_block + 8 * n;
+    rgb_spds.magenta.samples = g_block + 9 * n;
+    rgb_spds.yellow.samples = g_block + 10 * n;
+    spd_stack.capacity = stack_capacity;
+    spd_stack.allocated = 0;
+    spd_stack.base = g_block + 11 * n;
+    spd_stack.next = spd_stack.base;
+}
+/* tables: [11][n] = rw, x, y, z, white, red, green, blue, cyan, magenta, yellow */
+REF_API void ref_set_tables(const double *tables) { memcpy(g_block, tables, (size_t)11 * number_of_spectrum_samples * sizeof(f64)); }
+
+/* ---- geometry.c / rng.c / spectrum.c, whole files ------------------------------------------ */
+static vec3 v3_in(const double a[3]) { vec3 v; v.x = a[0]; v.y = a[1]; v.z = a[2]; return v; }
+static void v3_out(vec3 v, double o[3]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
+static void m_out(mat3x3 m, double o[9])
+{
+    for (int c = 0; c < 3; c += 1) for (int r = 0; r < 3; r += 1) o[3 * c + r] = m.columns[c].xyz[r];
+}
+REF_API double ref_line_sphere(const double o[3], const double d[3], const double c[3], double r)
+{
+    return line_sphere_intersection(v3_in(o), v3_in(d), v3_in(c), r);
+}
+REF_API double ref_line_plane(const double o[3], const double d[3], const double p[3], const double n[3], const double u[3], const double v[3])
+{
+    return line_plane_intersection(v3_in(o), v3_in(d), v3_in(p), v3_in(n), v3_in(u), v3_in(v));
+}
+REF_API void ref_reflect(const double v[3], const double n[3], double out[3]) { v3_out(vec3_reflect(v3_in(v), v3_in(n)), out); }
+REF_API void ref_transmit(const double v[3], const double n[3], double ir, double tr, double out[3])
+{
+    v3_out(vec3_transmit(v3_in(v), v3_in(n), ir, tr), out);
+}
+REF_API void ref_rotation_between(const double v[3], const double w[3], double m[9]) { m_out(find_rotation_between_vectors(v3_in(v), v3_in(w)), m); }
+REF_API void ref_rotation_about_axis(const double a[3], double angle, double m[9]) { m_out(rotation_about_axis(v3_in(a), angle), m); }
+REF_API void ref_create_plane(const double o[3], const double pu[3], const double pv[3], double u[3], double v[3], double n[3])
+{
+    vec3 po, u_, v_, n_;
+    create_plane_from_points(v3_in(o), v3_in(pu), v3_in(pv), &po, &u_, &v_, &n_);
+    v3_out(u_, u); v3_out(v_, v); v3_out(n_, n);
+}
+REF_API void ref_uniform_sample_sphere(double out[3]) { v3_out(uniform_sample_sphere(), out); }
+REF_API void ref_uniform_sample_disc(double out[3]) { v3_out(uniform_sample_disc(), out); }
+REF_API void ref_rgb_to_spectrum(const double rgb[3], double *dst)
+{
+    rgb_f64 c; c.r = rgb[0]; c.g = rgb[1]; c.b = rgb[2];
+    spectrum s; s.samples = dst;
+    rgb_f64_to_spectrum(c, s);
+}
+REF_API void ref_spectrum_to_xyz(const double *spd, double xyz[3])
+{
+    spectrum s; s.samples = (f64 *)spd;
+    rgb_f64 r = spectrum_to_xyz(s);
+    xyz[0] = r.x; xyz[1] = r.y; xyz[2] = r.z;
+}
+REF_API void ref_spectrum_to_rgb(const double *spd, double rgb[3])
+{
+    spectrum s; s.samples = (f64 *)spd;
+    rgb_f64 r = spectrum_to_rgb_f64(s);
+    rgb[0] = r.r; rgb[1] = r.g; rgb[2] = r.b;
+}
+REF_API void ref_blackbody(double temperature, double *dst)
+{
+    spectrum s; s.samples = dst;
+    generate_blackbody_spectrum(s, temperature);
+}
+REF_API double ref_value_at_wl(const double *spd, double wl)
+{
+    spectrum s; s.samples = (f64 *)spd;
+    return value_at_wl(s, wl);
+}
+REF_API void ref_init_camera(drt_camera *out, const double position[3], const double target[3], double roll, double fov,
+                             double fdepth, double flength, double aperture, uint32_t w, uint32_t h)
+{
+    camera_input_data in;
+    memset(&in, 0, sizeof(in));
+    in.position = v3_in(position); in.target = v3_in(target);
+    in.roll = roll; in.fov = fov; in.fdepth = fdepth; in.flength = flength; in.aperture = aperture;
+    in.width_px = w; in.height_px = h;
+    camera_data cam;
+    memset(&cam, 0, sizeof(cam));
+    init_camera(&cam, &in);
+    v3_out(cam.forward, out->forward); v3_out(cam.right, out->right); v3_out(cam.up, out->up);
+    v3_out(cam.aperture_position, out->aperture_position);
+    out->aperture_radius = cam.aperture_radius; out->focal_depth = cam.focal_depth; out->focal_length = cam.focal_length;
+    v3_out(cam.film_bottom_left, out->film_bottom_left);
+    out->pixel_width = cam.pixel_width; out->pixel_height = cam.pixel_height;
+}
+
+/* ---- bdsf.c ---------------------------------------------------------------------------------- */
+REF_API double ref_ggx(const double sn[3], const double mn[3], double r) { return ggx(v3_in(sn), v3_in(mn), r); }
+REF_API double ref_ggx_att(const double v[3], const double sn[3], const double mn[3], double r) { return ggx_att(v3_in(v), v3_in(sn), v3_in(mn), r); }
+REF_API void ref_fs_dielectric_reflectance(const double *ir, const double *tr, double inc_cos, double *out)
+{
+    spectrum o, i, t; o.samples = out; i.samples = (f64 *)ir; t.samples = (f64 *)tr;
+    fs_dielectric_reflectance(o, i, t, inc_cos);
+}
+REF_API void ref_fs_conductor_reflectance(const double *ir, const double *tr, const double *te, double inc_cos, double *out)
+{
+    spectrum o, i, t, e; o.samples = out; i.samples = (f64 *)ir; t.samples = (f64 *)tr; e.samples = (f64 *)te;
+    fs_conductor_reflectance(o, i, t, e, inc_cos);
+}
+
+/* ---- scene in the reference's own structs ---------------------------------------------------- */
+static scene_data g_scene;
+static f64 *g_scene_spds = NULL;
+static f64 *g_zero = NULL;
+
+static spectrum spd_at(const drt_scene *sc, int32_t idx)
+{
+    spectrum s;
+    s.samples = idx < 0 ? g_zero : g_scene_spds + (size_t)idx * sc->num_wavelengths;
+    return s;
+}
+
+/* Builds scene_data from the boundary structs; sets the spectral grid and the 11 tables from
+ * SPD indices 0..10 of the block (the host loader's layout: rw,x,y,z,white,r,g,b,c,m,y). */
+REF_API void ref_set_scene(const drt_scene *sc)
+{
+    uint32_t S = sc->num_wavelengths;
+    ref_set_grid(S, sc->min_wavelength, sc->wavelength_interval);
+    if (sc->num_spds >= 11) ref_set_tables(sc->spds);
+    /* colour-matching tables may sit elsewhere in the block */
+    memcpy(cmfs.rw.samples, sc->spds + (size_t)sc->cmf_rw * S, S * sizeof(f64));
+    memcpy(cmfs.x.samples, sc->spds + (size_t)sc->cmf_x * S, S * sizeof(f64));
+    memcpy(cmfs.y.samples, sc->spds + (size_t)sc->cmf_y * S, S * sizeof(f64));
+    memcpy(cmfs.z.samples, sc->spds + (size_t)sc->cmf_z * S, S * sizeof(f64));
+    free(g_scene_spds); free(g_zero); free(g_scene.surfaces); free(g_scene.scene_materials);
+    g_scene_spds = (f64 *)malloc((size_t)sc->num_spds * S * sizeof(f64));
+    memcpy(g_scene_spds, sc->spds, (size_t)sc->num_spds * S * sizeof(f64));
+    g_zero = (f64 *)calloc(S, sizeof(f64));
+    memset(&g_scene, 0, sizeof(g_scene));
+    g_scene.num_surfaces = sc->num_surfaces;
+    g_scene.num_scene_materials = sc->num_materials;
+    char *sbuf = (char *)calloc(sc->num_surfaces ? sc->num_surfaces : 1, sizeof(object_geometry) + sizeof(u32));
+    g_scene.surfaces = (object_geometry *)sbuf;
+    g_scene.surface_material_indices = (u32 *)(sbuf + (size_t)(sc->num_surfaces ? sc->num_surfaces : 1) * sizeof(object_geometry));
+    g_scene.scene_materials = (object_material *)calloc(sc->num_materials, sizeof(object_material));
+    for (uint32_t i = 0; i < sc->num_materials; i += 1)
+    {
+        const drt_material *m = &sc->materials[i];
+        object_material *d = &g_scene.scene_materials[i];
+        d->is_black_body = m->is_black_body;
+        d->is_emissive = m->is_emissive;
+        d->shininess = m->shininess;
+        d->roughness = m->roughness;
+        d->emission_spd = spd_at(sc, m->emission_spd);
+        d->diffuse_spd = spd_at(sc, m->diffuse_spd);
+        d->glossy_spd = spd_at(sc, m->glossy_spd);
+        d->mirror_spd = spd_at(sc, m->mirror_spd);
+        d->refract_spd = spd_at(sc, m->refract_spd);
+        d->extinct_spd = spd_at(sc, m->extinct_spd);
+        d->num_bdsfs = m->num_bdsfs;
+        for (uint32_t j = 0; j < m->num_bdsfs; j += 1) d->bdsfs[j] = bdsf_list[m->bdsfs[j]];
+        d->sample_direction = dir_func_list[m->dir_func];
+    }
+    g_scene.base_material = &g_scene.scene_materials[sc->base_material];
+    g_scene.escape_material = &g_scene.scene_materials[sc->escape_material];
+    for (uint32_t i = 0; i < sc->num_surfaces; i += 1)
+    {
+        const drt_surface *s = &sc->surfaces[i];
+        object_geometry *d = &g_scene.surfaces[i];
+        d->type = (geometry_type)s->type;
+        d->position = v3_in(s->position);
+        if (s->type == GEO_TYPE_SPHERE) d->radius = s->radius;
+        else if (s->type == GEO_TYPE_PLANE)
+        {
+            d->normal = v3_in(s->normal);
+            d->u = v3_in(s->u);
+            d->v = v3_in(s->v);
+        }
+        g_scene.surface_material_indices[i] = s->material;
+    }
+}
+
+static camera_data cam_in(const drt_camera *c)
+{
+    camera_data cam;
+    memset(&cam, 0, sizeof(cam));
+    cam.forward = v3_in(c->forward); cam.right = v3_in(c->right); cam.up = v3_in(c->up);
+    cam.aperture_position = v3_in(c->aperture_position);
+    cam.aperture_radius = c->aperture_radius; cam.focal_depth = c->focal_depth; cam.focal_length = c->focal_length;
+    cam.film_bottom_left = v3_in(c->film_bottom_left);
+    cam.pixel_width = c->pixel_width; cam.pixel_height = c->pixel_height;
+    return cam;
+}
+
+/* The same plain point record as the oracle's drt_oracle_point. */
+typedef struct
+{
+    double position[3], normal[3], out[3];
+    double on_dot, trans_wl;
+    uint32_t surface_material, incident_material, transmit_material;
+} ref_point;
+
+static scene_point point_in(const ref_point *a)
+{
+    scene_point p;
+    memset(&p, 0, sizeof(p));
+    p.position = v3_in(a->position); p.normal = v3_in(a->normal); p.out = v3_in(a->out);
+    p.on_dot = a->on_dot; p.trans_wl = a->trans_wl;
+    p.surface_material = &g_scene.scene_materials[a->surface_material];
+    p.incident_material = &g_scene.scene_materials[a->incident_material];
+    p.transmit_material = &g_scene.scene_materials[a->transmit_material];
+    return p;
+}
+static void point_out(const scene_point *p, ref_point *a)
+{
+    v3_out(p->position, a->position); v3_out(p->normal, a->normal); v3_out(p->out, a->out);
+    a->on_dot = p->on_dot; a->trans_wl = p->trans_wl;
+    a->surface_material = (uint32_t)(p->surface_material - g_scene.scene_materials);
+    a->incident_material = p->incident_material ? (uint32_t)(p->incident_material - g_scene.scene_materials) : 0;
+    a->transmit_material = p->transmit_material ? (uint32_t)(p->transmit_material - g_scene.scene_materials) : 0;
+}
+
+REF_API void ref_bdsf_func(uint32_t id, const ref_point *ap, const double incoming[3], double *result)
+{
+    scene_point p = point_in(ap);
+    spectrum r; r.samples = result;
+    bdsf_list[id](r, &p, v3_in(incoming));
+}
+REF_API void ref_bdsf(const ref_point *ap, const double incoming[3], double *reflectance)
+{
+    scene_point p = point_in(ap);
+    spectrum r; r.samples = reflectance;
+    bdsf(r, &p, v3_in(incoming));
+}
+REF_API void ref_dir_func(uint32_t id, const ref_point *ap, double dir[3], double *recip_pdf)
+{
+    scene_point p = point_in(ap);
+    vec3 v; v.x = v.y = v.z = 0.0;
+    f64 pdf = 0.0;
+    dir_func_list[id](&v, &pdf, &p);
+    v3_out(v, dir);
+    *recip_pdf = pdf;
+}
+REF_API int ref_find_ray_intersection(const double o[3], const double d[3], ref_point *ap)
+{
+    scene_point p;
+    memset(&p, 0, sizeof(p));
+    find_ray_intersection(&p, &g_scene, v3_in(o), v3_in(d));
+    if (ap) point_out(&p, ap);
+    if (p.surface_material == g_scene.escape_material && !p.surface) return -1;
+    return (int)(p.surface - g_scene.surfaces);
+}
+REF_API int ref_points_mutually_visible(const double p0[3], const double p1[3]) { return (int)points_mutually_visible(v3_in(p0), v3_in(p1), &g_scene); }
+REF_API void ref_direct_light(const ref_point *ap, double *contribution)
+{
+    scene_point p = point_in(ap);
+    spectrum c; c.samples = contribution;
+    direct_light_contribution(c, &p, &g_scene);
+}
+
+/* One path through the reference's own sample_scene(). */
+REF_API void ref_sample_scene(const drt_camera *c, const drt_params *p, uint32_t x, uint32_t y, uint32_t sample,
+                              double *contribution, double *filter)
+{
+    camera_data cam = cam_in(c);
+    ref_seed_path(p->seed + (((uint64_t)sample * p->height + y) * (uint64_t)p->width + x));
+    spectrum s; s.samples = contribution;
+    sample_scene(s, filter, x, y, &g_scene, &cam, p->max_depth, (film_sample_scheme)p->pixel_scheme);
+}
+
+/*
+ * Closest-hit index sequence of one path. cast_ray() does not report which surfaces it hit, so
+ * this replays the same seed through a loop of the reference's OWN functions in cast_ray's order
+ * (find_ray_intersection / direct_light_contribution / sample_direction / bdsf) and logs
+ * intersection.surface. The caller checks that the spectrum it produces is bitwise the one
+ * sample_scene() gives, which ties the logged sequence to the real cast_ray.
+ */
+REF_API int ref_trace_hits(const drt_camera *c, const drt_params *p, uint32_t x, uint32_t y, uint32_t sample,
+                           int32_t *hit_seq, double *contribution)
+{
+    camera_data cam = cam_in(c);
+    ref_seed_path(p->seed + (((uint64_t)sample * p->height + y) * (uint64_t)p->width + x));
+    uint32_t S = number_of_spectrum_samples;
+    vec3 ps = sample_pixel_point((film_sample_scheme)p->pixel_scheme);
+    f64 film_x = ((f64)x + ps.x) * cam.pixel_width;
+    f64 film_y = ((f64)y + ps.y) * cam.pixel_height;
+    vec3 pp = vec3_sum(vec3_sum(vec3_mul_by_f64(cam.right, film_x), vec3_mul_by_f64(cam.up, film_y)), cam.film_bottom_left);
+    if (cam.aperture_radius > 0.0) return -1; /* pinhole only; thin-lens paths are compared through spectra */
+    vec3 ro = pp;
+    vec3 rd = vec3_normalise(vec3_sub(cam.aperture_position, ro));
+    vec3 rd0 = rd;
+    spectrum dst; dst.samples = contribution;
+    zero_spectrum(dst);
+    spectrum contrib = alloc_spd(), thr = alloc_spd(), refl = alloc_spd(), tmp = alloc_spd();
+    const_spectrum(thr, 1.0);
+    scene_point ip;
+    memset(&ip, 0, sizeof(ip));
+    int scans = 0;
+    for (uint32_t d = 0; d < p->max_depth; d += 1) hit_seq[d] = -2;
+    for (uint32_t depth = 0; depth < p->max_depth; depth += 1)
+    {
+        ip.surface = NULL;
+        find_ray_intersection(&ip, &g_scene, ro, rd);
+        int missed = (ip.surface_material == g_scene.escape_material && ip.surface == NULL);
+        hit_seq[depth] = missed ? -1 : (int32_t)(ip.surface - g_scene.surfaces);
+        scans += 1;
+        object_material *mat = ip.surface_material;
+        if (mat->is_black_body && !mat->is_emissive) break;
+        else if (mat->is_black_body && mat->is_emissive)
+        {
+            spectral_mul_by_spectrum(tmp, thr, mat->emission_spd);
+            spectral_sum(dst, dst, tmp);
+            break;
+        }
+        direct_light_contribution(contrib, &ip, &g_scene);
+        spectral_mul_by_spectrum(tmp, thr, contrib);
+        spectral_sum(dst, dst, tmp);
+        vec3 in; f64 dir_pdf;
+        mat->sample_direction(&in, &dir_pdf, &ip);
+        bdsf(refl, &ip, in);
+        spectral_mul_by_scalar(refl, refl, dir_pdf);
+        spectral_mul_by_spectrum(thr, thr, refl);
+        rd = in;
+        ro = ip.position;
+    }
+    free_spd(tmp); free_spd(refl); free_spd(thr); free_spd(contrib);
+    spectral_mul_by_scalar(dst, dst, vec3_dot(rd0, cam.forward) * 1.0);
+    (void)S;
+    return scans;
+}
+
+/* The pixel loop of render_image (src/daily_ray_trace.c:710-745) over a tile, with the per-path
+ * seeding; film buffers are accumulated into with the reference's spectral ops in its order. */
+REF_API void ref_render_tile(const drt_camera *c, const drt_params *p, double *pixels, double *avgs, double *vars)
+{
+    camera_data cam = cam_in(c);
+    uint32_t S = number_of_spectrum_samples;
+    f64 *cbuf = (f64 *)calloc(S + 1, sizeof(f64));
+    spectrum contribution; contribution.samples = cbuf;
+    f64 *filter = &cbuf[S];
+    spectrum tmp0 = alloc_spd(), tmp1 = alloc_spd();
+    uint32_t stride = p->row_stride ? p->row_stride : 1;
+    for (uint32_t s = 0; s < p->spp; s += 1)
+    {
+        uint32_t sample = p->first_sample + s;
+        for (uint32_t j = 0; j < p->tile_h; j += 1)
+        {
+            uint32_t y = p->y0 + j * stride;
+            for (uint32_t i = 0; i < p->tile_w; i += 1)
+            {
+                uint32_t x = p->x0 + i;
+                uint64_t off = (uint64_t)j * p->tile_w + i;
+                spectrum dp, da, dv;
+                dp.samples = pixels + off * (S + 1);
+                da.samples = avgs + off * S;
+                dv.samples = vars + off * S;
+                ref_seed_path(p->seed + (((uint64_t)sample * p->height + y) * (uint64_t)p->width + x));
+                sample_scene(contribution, filter, x, y, &g_scene, &cam, p->max_depth, (film_sample_scheme)p->pixel_scheme);
+                spectral_sum(dp, dp, contribution);
+                dp.samples[S] += *filter;
+                copy_spectrum(tmp0, da);
+                spectral_sub(tmp0, contribution, tmp0);
+                copy_spectrum(tmp1, tmp0);
+                spectral_div_by_scalar(tmp0, tmp0, (f64)(sample + 1));
+                spectral_sum(da, da, tmp0);
+                spectral_sub(tmp0, contribution, da);
+                spectral_mul_by_spectrum(tmp0, tmp1, tmp0);
+                spectral_sum(dv, dv, tmp0);
+            }
+        }
+    }
+    free_spd(tmp1); free_spd(tmp0);
+    free(cbuf);
+}
+
+REF_API int ref_version(void) { return 1; }
