@@ -1,0 +1,914 @@
+/*
+ * drt_kernels.h -- the two hot kernels and their data layouts.
+ *
+ *   drt_trace_kernel   one ray per lane. sample_scene's ray generation + cast_ray's geometry:
+ *                      closest hit, next-event light samples + shadow rays, BDSF coefficient
+ *                      evaluation, direction sampling, xorshift RNG. Scene primitives, lights and
+ *                      materials are SoA in HBM, staged into LDS once per workgroup. Lanes whose
+ *                      path has ended pick up the next path (wave ballot + prefix count), so a
+ *                      wave stays full until the batch runs out.
+ *                      Output: one compact record per shaded vertex (layout below).
+ *   drt_shade_kernel   one wavelength per lane, one pixel per wave. Replays the vertex records of
+ *                      the pixel's samples over the wavelengths (SPD tables in LDS), i.e. bdsf()
+ *                      sums, light weighting, throughput products, emissive hits, vignette; then
+ *                      the film update of render_image (sum, filter sum, running mean / variance).
+ *                      Throughput and radiance live in registers; only the film touches HBM.
+ *
+ * Reference lines each piece follows are cited at the piece.
+ */
+#pragma once
+
+#include "drt_device.h"
+#include "../../include/drt_hip.h"
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Device-side scene                                                                               */
+
+/* surface SoA field indices: surf[f * n_surf + i] */
+enum
+{
+    SF_PX = 0, SF_PY, SF_PZ, SF_RADIUS,
+    SF_NX, SF_NY, SF_NZ,
+    SF_UNX, SF_UNY, SF_UNZ, /* u / |u| */
+    SF_VNX, SF_VNY, SF_VNZ, /* v / |v| */
+    SF_ULEN, SF_VLEN,
+    SF_COUNT
+};
+/* light SoA field indices: lights[f * n_lights + l] */
+enum
+{
+    LF_PX = 0, LF_PY, LF_PZ, LF_RADIUS,
+    LF_UX, LF_UY, LF_UZ,
+    LF_VX, LF_VY, LF_VZ,
+    LF_PDF, /* sphere: (4 pi R) R ; plane: |u x v| ; point: 1 */
+    LF_COUNT
+};
+
+/* what a material's bdsf list needs evaluated per (vertex, incoming direction) */
+enum
+{
+    NEED_GLOSSY = 1u, /* bp_glossy_bdsf: pow term           */
+    NEED_EQR    = 2u, /* exact test against the mirror direction (mirror / fs_conductor / fs_dielectric_reflectance) */
+    NEED_EQT    = 4u, /* exact test against the refracted direction (fs_dielectric_transmittance)                  */
+    NEED_CT     = 8u  /* ct_conductor_bdsf: half-vector cosine + GGX coefficient */
+};
+
+struct DevMaterial
+{
+    uint32_t is_black_body, is_emissive, num_bdsfs, dir_func;
+    uint32_t needs, pad0;
+    int32_t  emission_spd, diffuse_spd, glossy_spd, mirror_spd, refract_spd, extinct_spd;
+    double   shininess, roughness;
+    double   refract_i0, refract_i1; /* refract_spd at the two samples around trans_wl (value_at_wl) */
+    uint32_t bdsfs[DRT_MAX_BDSFS];
+};
+
+struct DevScene
+{
+    uint32_t n_surf, n_lights, n_mat, S;
+    uint32_t n_spd, base_mat, escape_mat, trans_i0;
+    double   trans_wl, trans_w0, trans_w1; /* value_at_wl at 630 nm: i0, i0+1 and their wavelengths */
+    const double      *surf;       /* [SF_COUNT][n_surf] */
+    const uint32_t    *surf_type;  /* [n_surf] */
+    const uint32_t    *surf_mat;   /* [n_surf] */
+    const double      *lights;     /* [LF_COUNT][n_lights] */
+    const uint32_t    *light_type; /* [n_lights] */
+    const uint32_t    *light_mat;  /* [n_lights] material of the emissive surface */
+    const DevMaterial *mats;       /* [n_mat] */
+    const double      *spds;       /* [n_spd][S] */
+    const double      *inv_pi_diffuse; /* unused slot kept for layout stability */
+};
+
+struct DevCamera
+{
+    V3     forward, right, up, aperture_position, film_bottom_left;
+    double aperture_radius, focal_depth, pixel_width, pixel_height;
+};
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Vertex records (trace -> shade). All 8-byte words.                                              */
+/*                                                                                                  */
+/*  path header (8 words):  w0 = n_shaded | term<<32   (term: 0 none/escape, 1 emissive hit)       */
+/*                          w1 = emission SPD index of the emissive hit                            */
+/*                          w2 = vignette (double)                                                 */
+/*  vertex fixed part (8):  w0 = surface material | incident material<<32                          */
+/*                          w1 = transmit material | sampled-direction flags<<32                   */
+/*                          w2 = on_dot, w3 = 1/pdf of the sampled direction                       */
+/*                          w4..w7 = |n.in|, glossy pow term, |n.m|, GGX coefficient  (sampled dir) */
+/*  per light (8):          w0 = emission SPD index | flags<<32, w1 = atten * area                 */
+/*                          w2..w5 = the same four coefficients for the light direction            */
+/*  flags: bit0 in == mirror direction, bit1 in == refracted direction, bit2 light visible         */
+
+#define REC_HEADER_WORDS 8
+#define REC_VERTEX_WORDS 8
+#define REC_LIGHT_WORDS 8
+#define FLAG_EQR 1u
+#define FLAG_EQT 2u
+#define FLAG_VISIBLE 4u
+
+struct TraceParams
+{
+    uint32_t width, height, x0, y0, tile_w, tile_h, row_stride;
+    uint32_t first_sample, n_samples, max_depth, pixel_scheme, record_hits;
+    uint64_t seed;
+    uint64_t n_pix, n_paths;
+    uint32_t vertex_words, path_words; /* record strides in 8-byte words */
+    uint32_t hits_sample_offset, pad;
+};
+
+struct EvalCoef
+{
+    double   a_in, spec, mn_dot, ct_coef;
+    uint32_t flags;
+};
+
+/* counters: [0] paths [1] closest-hit scans [2] shaded vertices [3] shadow scans [4] rng draws */
+#define DRT_NUM_COUNTERS 8
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Trace kernel pieces                                                                             */
+
+struct SceneView /* pointers into LDS (or HBM when the scene does not fit) */
+{
+    const double      *surf;
+    const uint32_t    *surf_type, *surf_mat;
+    const double      *lights;
+    const uint32_t    *light_type, *light_mat;
+    const DevMaterial *mats;
+    uint32_t           n_surf, n_lights;
+};
+
+__device__ __forceinline__ V3 sf3(const SceneView &sv, int f, uint32_t i)
+{
+    return v3(sv.surf[(f + 0) * sv.n_surf + i], sv.surf[(f + 1) * sv.n_surf + i], sv.surf[(f + 2) * sv.n_surf + i]);
+}
+
+__device__ __forceinline__ double surface_distance(const SceneView &sv, uint32_t i, uint32_t type, V3 o, V3 d)
+{
+    if (type == DRT_GEO_SPHERE) return line_sphere(o, d, sf3(sv, SF_PX, i), sv.surf[SF_RADIUS * sv.n_surf + i]);
+    return line_plane(o, d, sf3(sv, SF_PX, i), sf3(sv, SF_NX, i), sf3(sv, SF_UNX, i), sf3(sv, SF_VNX, i),
+                      sv.surf[SF_ULEN * sv.n_surf + i], sv.surf[SF_VLEN * sv.n_surf + i]);
+}
+
+/* points_mutually_visible, src/daily_ray_trace.c:238-270 */
+__device__ __forceinline__ bool points_mutually_visible(const SceneView &sv, V3 p0, V3 p1)
+{
+    V3 dir = v_normalise(v_sub(p1, p0));
+    V3 o = v_sum(p0, v_mul(dir, DRT_VIS_FUDGE));
+    double vis_dist = v_length(v_sub(p1, o)) - DRT_VIS_FUDGE;
+    bool visible = true;
+    for (uint32_t i = 0; i < sv.n_surf; i += 1)
+    {
+        uint32_t type = sv.surf_type[i];
+        if (type != DRT_GEO_SPHERE && type != DRT_GEO_PLANE) continue;
+        double dist = surface_distance(sv, i, type, o, dir);
+        if (visible && dist < vis_dist) visible = false; /* the reference breaks here; later surfaces cannot undo it */
+        if (!__any(visible)) break;
+    }
+    return visible;
+}
+
+struct HitPoint /* scene_point, src/daily_ray_trace.h:113-125 */
+{
+    V3       position, normal, out;
+    double   on_dot;
+    uint32_t surface_mat, incident_mat, transmit_mat;
+    int      index;
+};
+
+/* find_ray_intersection, src/daily_ray_trace.c:334-403 */
+__device__ __forceinline__ void find_ray_intersection(const SceneView &sv, const DevScene &sc, HitPoint &ip, V3 ro, V3 rd)
+{
+    double min_dist = DRT_INF;
+    int index = -1;
+    ro = v_sum(ro, v_mul(rd, DRT_VIS_FUDGE));
+    for (uint32_t i = 0; i < sv.n_surf; i += 1)
+    {
+        uint32_t type = sv.surf_type[i];
+        if (type != DRT_GEO_SPHERE && type != DRT_GEO_PLANE) continue;
+        double dist = surface_distance(sv, i, type, ro, rd);
+        if (dist < min_dist)
+        {
+            min_dist = dist;
+            index = (int)i;
+        }
+    }
+    ip.index = index;
+    if (index >= 0)
+    {
+        uint32_t type = sv.surf_type[index];
+        uint32_t smat = sv.surf_mat[index];
+        ip.position = v_sum(ro, v_mul(rd, min_dist));
+        if (type == DRT_GEO_SPHERE) ip.normal = v_normalise(v_sub(ip.position, sf3(sv, SF_PX, index)));
+        else ip.normal = sf3(sv, SF_NX, index);
+        ip.out = v_reverse(rd);
+        ip.on_dot = v_dot(ip.normal, ip.out);
+        ip.transmit_mat = smat;
+        ip.incident_mat = sc.base_mat;
+        if (ip.on_dot < 0.0)
+        {
+            if (type != DRT_GEO_PLANE)
+            {
+                ip.transmit_mat = sc.base_mat;
+                ip.incident_mat = smat;
+            }
+            ip.normal = v_reverse(ip.normal);
+            ip.on_dot = v_dot(ip.normal, ip.out);
+        }
+        ip.surface_mat = smat;
+    }
+    else ip.surface_mat = sc.escape_mat;
+}
+
+/* refractive indices at trans_wl: value_at_wl(refract_spd, 630), src/spectrum.c:150-162 */
+__device__ __forceinline__ double refract_at_trans_wl(const DevScene &sc, const DevMaterial &m)
+{
+    return drt_lerp(sc.trans_wl, sc.trans_w0, sc.trans_w1, m.refract_i0, m.refract_i1);
+}
+
+/* The per-direction scalars of every BDSF in the material's list (src/bdsf.c:105-186):
+ * what remains of bdsf(p, in) once the per-wavelength work is taken out. */
+__device__ __forceinline__ EvalCoef eval_coefficients(const DevScene &sc, const SceneView &sv, const HitPoint &ip, V3 in)
+{
+    const DevMaterial &mat = sv.mats[ip.surface_mat];
+    EvalCoef e;
+    e.a_in = __builtin_fabs(v_dot(ip.normal, in)); /* bp_diffuse :108, bp_glossy :118 */
+    e.spec = 0.0;
+    e.mn_dot = 0.0;
+    e.ct_coef = 0.0;
+    e.flags = 0;
+    uint32_t needs = mat.needs;
+    if (needs & NEED_GLOSSY) /* :113-115 */
+    {
+        V3 bisector = v_normalise(v_sum(ip.out, in));
+        double nb = v_dot(ip.normal, bisector);
+        e.spec = pow((0.0 > nb) ? 0.0 : nb, mat.shininess);
+    }
+    if (needs & NEED_EQR) /* :123-124, :136-137, :150-151 */
+    {
+        if (v_equal(in, v_reflect(v_reverse(ip.out), ip.normal))) e.flags |= FLAG_EQR;
+    }
+    if (needs & NEED_EQT) /* :163-168 */
+    {
+        double ir = refract_at_trans_wl(sc, sv.mats[ip.incident_mat]);
+        double tr = refract_at_trans_wl(sc, sv.mats[ip.transmit_mat]);
+        if (v_equal(in, v_transmit(v_reverse(ip.out), ip.normal, ir, tr))) e.flags |= FLAG_EQT;
+    }
+    if (needs & NEED_CT) /* :176-184 */
+    {
+        V3 micro_normal = v_normalise(v_sum(ip.out, in));
+        e.mn_dot = __builtin_fabs(v_dot(ip.normal, micro_normal));
+        e.ct_coef = ggx_att(ip.out, ip.normal, micro_normal, mat.roughness) * (1.0 / (4.0 * ip.on_dot));
+    }
+    return e;
+}
+
+/* Direction samplers, src/bdsf.c:188-292; they return the reciprocal pdf */
+__device__ __forceinline__ void sample_direction(const DevScene &sc, const SceneView &sv, const HitPoint &ip, uint64_t &rs,
+                                                 uint32_t &draws, V3 &dir, double &recip_pdf)
+{
+    const DevMaterial &mat = sv.mats[ip.surface_mat];
+    const V3 zaxis = v3(0.0, 0.0, 1.0);
+    switch (mat.dir_func)
+    {
+        case DRT_DIRF_cos_weighted_sample_hemisphere: /* :200-213 */
+        {
+            V3 q;
+            for (;;)
+            {
+                q = uniform_sample_disc(rs, draws);
+                if (v_dot(q, q) < 1.0) break;
+            }
+            q.z = __builtin_sqrt(1.0 - v_dot(q, q));
+            M33 r = rotation_between(zaxis, ip.normal);
+            dir = m_vmul(r, q);
+            recip_pdf = DRT_PI / v_dot(ip.normal, dir);
+            break;
+        }
+        case DRT_DIRF_uniform_sample_hemisphere: /* :191-198 */
+        {
+            V3 s = uniform_sample_sphere(rs, draws);
+            M33 r = rotation_between(zaxis, ip.normal);
+            dir = m_vmul(r, s);
+            recip_pdf = 2.0 * DRT_PI;
+            break;
+        }
+        case DRT_DIRF_sample_specular_direction: /* :215-220 */
+        {
+            dir = v_reflect(v_reverse(ip.out), ip.normal);
+            recip_pdf = 1.0;
+            break;
+        }
+        case DRT_DIRF_sample_transmit_direction: /* :222-234 */
+        {
+            double ir = refract_at_trans_wl(sc, sv.mats[ip.incident_mat]);
+            double tr = refract_at_trans_wl(sc, sv.mats[ip.transmit_mat]);
+            dir = v_transmit(v_reverse(ip.out), ip.normal, ir, tr);
+            recip_pdf = 1.0;
+            break;
+        }
+        case DRT_DIRF_sample_reflect_or_transmit_direction: /* :236-259 */
+        {
+            const DevMaterial &im = sv.mats[ip.incident_mat];
+            const DevMaterial &tm = sv.mats[ip.transmit_mat];
+            /* value_at_wl(reflectance spectrum, 630) needs the Fresnel term at the two bracketing samples */
+            double inc_sin_sq = 1.0 - ip.on_dot * ip.on_dot;
+            double r0 = dielectric_reflectance(im.refract_i0, tm.refract_i0, ip.on_dot, inc_sin_sq);
+            double r1 = dielectric_reflectance(im.refract_i1, tm.refract_i1, ip.on_dot, inc_sin_sq);
+            double rd = drt_lerp(sc.trans_wl, sc.trans_w0, sc.trans_w1, r0, r1);
+            double ir = refract_at_trans_wl(sc, im);
+            double tr = refract_at_trans_wl(sc, tm);
+            double f = drt_rng(rs, draws);
+            V3 w = v_reverse(ip.out);
+            if (f < rd)
+            {
+                dir = v_reflect(w, ip.normal);
+                recip_pdf = 1.0 / rd;
+            }
+            else
+            {
+                dir = v_transmit(w, ip.normal, ir, tr);
+                recip_pdf = 1.0 / (1.0 - rd);
+            }
+            break;
+        }
+        case DRT_DIRF_sample_ct_direction: /* :261-292 */
+        {
+            do
+            {
+                double f = drt_rng(rs, draws);
+                double g = drt_rng(rs, draws);
+                double phi_mn = (2.0 * DRT_PI) * g;
+                double tan_mn = (mat.roughness * __builtin_sqrt(f)) / __builtin_sqrt(1.0 - f);
+                double cos_mn = 1.0 / __builtin_sqrt(1.0 + tan_mn * tan_mn);
+                double sin_mn = __builtin_sqrt(1.0 - cos_mn * cos_mn);
+                double sp, cp;
+                drt_sincos(phi_mn, sp, cp);
+                V3 micro_normal = v3(sin_mn * cp, sin_mn * sp, cos_mn);
+                M33 r = rotation_between(zaxis, ip.normal);
+                micro_normal = m_vmul(r, micro_normal);
+                double sn_mn_dot = v_dot(ip.normal, micro_normal);
+                if (sn_mn_dot < 0.0)
+                {
+                    micro_normal = v_reverse(micro_normal);
+                    sn_mn_dot = -sn_mn_dot;
+                }
+                double o_mn_dot = v_dot(ip.out, micro_normal);
+                dir = v_reflect(v_reverse(ip.out), micro_normal);
+                double d = ggx(ip.normal, micro_normal, mat.roughness) * sn_mn_dot;
+                recip_pdf = ((4.0 * o_mn_dot) / d);
+            } while (v_dot(dir, ip.normal) < 0.0);
+            break;
+        }
+        default:
+            dir = v3(0.0, 0.0, 0.0);
+            recip_pdf = 0.0;
+            break;
+    }
+}
+
+__device__ __forceinline__ void store_coef(uint64_t *w, const EvalCoef &e)
+{
+    w[0] = (uint64_t)__double_as_longlong(e.a_in);
+    w[1] = (uint64_t)__double_as_longlong(e.spec);
+    w[2] = (uint64_t)__double_as_longlong(e.mn_dot);
+    w[3] = (uint64_t)__double_as_longlong(e.ct_coef);
+}
+
+/* Camera ray: sample_pixel_point + sample_scene's ray set-up, src/daily_ray_trace.c:550-607 */
+__device__ __forceinline__ void camera_ray(const DevCamera &cam, uint32_t scheme, uint32_t x, uint32_t y, uint64_t &rs,
+                                           uint32_t &draws, V3 &ro, V3 &rd)
+{
+    double px = 0.0, py = 0.0;
+    if (scheme == DRT_FILM_SAMPLE_CENTER) { px = 0.5; py = 0.5; }
+    else if (scheme == DRT_FILM_SAMPLE_RANDOM) { px = drt_rng(rs, draws); py = drt_rng(rs, draws); }
+    double film_x = ((double)x + px) * cam.pixel_width;
+    double film_y = ((double)y + py) * cam.pixel_height;
+    V3 bottom = v_mul(cam.up, film_y);
+    V3 left = v_mul(cam.right, film_x);
+    V3 pixel_point = v_sum(v_sum(left, bottom), cam.film_bottom_left);
+    if (cam.aperture_radius > 0.0)
+    {
+        V3 focus_dir = v_normalise(v_sub(cam.aperture_position, pixel_point));
+        focus_dir = v_mul(focus_dir, cam.focal_depth / v_dot(focus_dir, cam.forward));
+        V3 focus_point = v_sum(pixel_point, focus_dir);
+        M33 r = rotation_between(v3(0.0, 0.0, 1.0), cam.forward);
+        V3 disc_point = v_mul(uniform_sample_disc(rs, draws), cam.aperture_radius);
+        V3 lens_point = m_vmul(r, disc_point);
+        ro = v_sum(cam.aperture_position, lens_point);
+        rd = v_normalise(v_sub(focus_point, ro));
+    }
+    else
+    {
+        ro = pixel_point;
+        rd = v_normalise(v_sub(cam.aperture_position, ro));
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* The trace kernel                                                                                */
+
+#define TRACE_BLOCK 256
+
+/* LDS carve-up (8-byte aligned): surfaces, lights, then u32 tables, then materials (see trace_lds_bytes in the launcher) */
+
+template <bool SCENE_IN_LDS>
+__global__ __launch_bounds__(TRACE_BLOCK) void drt_trace_kernel(DevScene sc, DevCamera cam, TraceParams tp,
+                                                                 uint64_t *__restrict__ records, int32_t *__restrict__ hits,
+                                                                 unsigned long long *__restrict__ counters,
+                                                                 unsigned long long *__restrict__ work_counter)
+{
+    extern __shared__ double lds_raw[];
+    SceneView sv;
+    sv.n_surf = sc.n_surf;
+    sv.n_lights = sc.n_lights;
+    if (SCENE_IN_LDS)
+    {
+        /* stage the SoA scene: coalesced HBM reads, one pass per table */
+        double *l_surf = lds_raw;
+        double *l_lights = l_surf + (size_t)SF_COUNT * sc.n_surf;
+        uint32_t *l_u32 = (uint32_t *)(l_lights + (size_t)LF_COUNT * sc.n_lights);
+        uint32_t n_u32 = 2 * sc.n_surf + 2 * sc.n_lights;
+        DevMaterial *l_mats = (DevMaterial *)((char *)l_u32 + (((size_t)n_u32 * 4 + 7) & ~(size_t)7));
+        for (uint32_t k = threadIdx.x; k < SF_COUNT * sc.n_surf; k += TRACE_BLOCK) l_surf[k] = sc.surf[k];
+        for (uint32_t k = threadIdx.x; k < LF_COUNT * sc.n_lights; k += TRACE_BLOCK) l_lights[k] = sc.lights[k];
+        for (uint32_t k = threadIdx.x; k < sc.n_surf; k += TRACE_BLOCK)
+        {
+            l_u32[k] = sc.surf_type[k];
+            l_u32[sc.n_surf + k] = sc.surf_mat[k];
+        }
+        for (uint32_t k = threadIdx.x; k < sc.n_lights; k += TRACE_BLOCK)
+        {
+            l_u32[2 * sc.n_surf + k] = sc.light_type[k];
+            l_u32[2 * sc.n_surf + sc.n_lights + k] = sc.light_mat[k];
+        }
+        const uint64_t *src = (const uint64_t *)sc.mats;
+        uint64_t *dst = (uint64_t *)l_mats;
+        for (uint32_t k = threadIdx.x; k < sc.n_mat * (uint32_t)(sizeof(DevMaterial) / 8); k += TRACE_BLOCK) dst[k] = src[k];
+        __syncthreads();
+        sv.surf = l_surf;
+        sv.lights = l_lights;
+        sv.surf_type = l_u32;
+        sv.surf_mat = l_u32 + sc.n_surf;
+        sv.light_type = l_u32 + 2 * sc.n_surf;
+        sv.light_mat = l_u32 + 2 * sc.n_surf + sc.n_lights;
+        sv.mats = l_mats;
+    }
+    else
+    {
+        sv.surf = sc.surf;
+        sv.lights = sc.lights;
+        sv.surf_type = sc.surf_type;
+        sv.surf_mat = sc.surf_mat;
+        sv.light_type = sc.light_type;
+        sv.light_mat = sc.light_mat;
+        sv.mats = sc.mats;
+    }
+
+    const uint32_t lane = threadIdx.x & 63u;
+    /* per-wave work queue: a wave draws chunks of consecutive path ids from the global counter and
+     * deals them to its idle lanes by ballot + prefix count */
+    const uint64_t CHUNK = 64ull * 16ull;
+    uint64_t chunk_next = 0, chunk_end = 0; /* wave-uniform */
+
+    uint32_t n_scans = 0, n_shaded = 0, n_shadow = 0, n_draws = 0, n_paths = 0;
+
+    /* per-lane path state */
+    bool alive = false;
+    bool exhausted = false; /* wave-uniform: no more work to draw */
+    uint64_t pid = 0, rs = 1;
+    uint32_t depth = 0, shaded = 0;
+    V3 ro = v3(0, 0, 0), rd = v3(0, 0, 0);
+    uint64_t *rec = nullptr;
+
+    for (;;)
+    {
+        /* ---- refill idle lanes ---- */
+        unsigned long long idle_mask = __ballot(!alive);
+        if (idle_mask != 0ull && !exhausted)
+        {
+            uint32_t want = (uint32_t)__popcll(idle_mask);
+            uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull)); /* prefix count among idle lanes */
+            uint64_t avail = chunk_end - chunk_next;
+            if (avail < want)
+            {
+                /* hand out what is left of the chunk first, then draw a new chunk */
+                if (!alive && rank < avail)
+                {
+                    pid = chunk_next + rank;
+                    alive = true;
+                }
+                uint32_t taken = (uint32_t)avail;
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(work_counter, (unsigned long long)CHUNK);
+                base = __shfl(base, 0);
+                if (base >= tp.n_paths)
+                {
+                    exhausted = true;
+                    chunk_next = chunk_end = 0;
+                }
+                else
+                {
+                    chunk_next = base;
+                    chunk_end = (base + CHUNK < tp.n_paths) ? base + CHUNK : tp.n_paths;
+                    uint64_t avail2 = chunk_end - chunk_next;
+                    bool fresh = false;
+                    if (!alive && rank >= taken && (uint64_t)(rank - taken) < avail2)
+                    {
+                        pid = chunk_next + (rank - taken);
+                        alive = true;
+                        fresh = true;
+                    }
+                    uint32_t used = (want - taken < avail2) ? (want - taken) : (uint32_t)avail2;
+                    chunk_next += used;
+                    (void)fresh;
+                }
+                /* lanes that got a path in either step start it below */
+            }
+            else
+            {
+                if (!alive)
+                {
+                    pid = chunk_next + rank;
+                    alive = true;
+                }
+                chunk_next += want;
+            }
+            /* start the newly assigned paths: lanes that were idle in idle_mask and are alive now */
+            bool started = alive && ((idle_mask >> lane) & 1ull);
+            if (started)
+            {
+                uint64_t s_local = pid / tp.n_pix;
+                uint64_t q = pid - s_local * tp.n_pix;
+                uint32_t j = (uint32_t)(q / tp.tile_w);
+                uint32_t i = (uint32_t)(q - (uint64_t)j * tp.tile_w);
+                uint32_t x = tp.x0 + i;
+                uint32_t y = tp.y0 + j * tp.row_stride;
+                uint32_t sample = tp.first_sample + (uint32_t)s_local;
+                uint64_t key = tp.seed + (((uint64_t)sample * (uint64_t)tp.height + (uint64_t)y) * (uint64_t)tp.width + (uint64_t)x);
+                rs = drt_splitmix64(key);
+                camera_ray(cam, tp.pixel_scheme, x, y, rs, n_draws, ro, rd);
+                depth = 0;
+                shaded = 0;
+                rec = records + pid * (uint64_t)tp.path_words;
+                /* vignette: dot(ray_direction, forward) of the PRIMARY ray, src/daily_ray_trace.c:614 */
+                rec[2] = (uint64_t)__double_as_longlong(v_dot(rd, cam.forward) * 1.0);
+                n_paths += 1;
+                if (tp.record_hits)
+                {
+                    int32_t *h = hits + ((uint64_t)tp.hits_sample_offset * tp.n_pix + pid) * tp.max_depth;
+                    for (uint32_t d = 0; d < tp.max_depth; d += 1) h[d] = -2;
+                }
+            }
+        }
+        if (!__any(alive)) break;
+
+        if (alive)
+        {
+            /* ---- one iteration of cast_ray's loop, src/daily_ray_trace.c:446-474 ---- */
+            HitPoint ip;
+            find_ray_intersection(sv, sc, ip, ro, rd);
+            n_scans += 1;
+            if (tp.record_hits) hits[((uint64_t)tp.hits_sample_offset * tp.n_pix + pid) * tp.max_depth + depth] = ip.index;
+            const DevMaterial &mat = sv.mats[ip.surface_mat];
+            bool terminal = false;
+            uint32_t term = 0, term_spd = 0;
+            if (mat.is_black_body && !mat.is_emissive) terminal = true;
+            else if (mat.is_black_body && mat.is_emissive)
+            {
+                terminal = true;
+                term = 1;
+                term_spd = (uint32_t)mat.emission_spd;
+            }
+            else
+            {
+                uint64_t *vrec = rec + REC_HEADER_WORDS + (uint64_t)shaded * tp.vertex_words;
+                /* direct_light_contribution, :272-332 -- light samples are drawn before the shadow test */
+                n_shaded += 1;
+                for (uint32_t l = 0; l < sv.n_lights; l += 1)
+                {
+                    uint32_t ltype = sv.light_type[l];
+                    V3 lpos = v3(sv.lights[LF_PX * sv.n_lights + l], sv.lights[LF_PY * sv.n_lights + l], sv.lights[LF_PZ * sv.n_lights + l]);
+                    double light_pdf = sv.lights[LF_PDF * sv.n_lights + l];
+                    double attenuation = 1.0;
+                    V3 light_position = lpos;
+                    if (ltype == DRT_GEO_POINT)
+                    {
+                        double dist = v_length(v_sub(light_position, ip.position));
+                        attenuation = ((4.0 * DRT_PI) * dist) * dist;
+                    }
+                    else if (ltype == DRT_GEO_SPHERE)
+                    {
+                        double u = drt_rng(rs, n_draws);
+                        double v = drt_rng(rs, n_draws);
+                        double r = __builtin_sqrt(1.0 - u * u);
+                        double t = (2.0 * DRT_PI) * v;
+                        double st, ct;
+                        drt_sincos(t, st, ct);
+                        V3 sp = v3(r * ct, r * st, u);
+                        light_position = v_sum(lpos, v_mul(sp, sv.lights[LF_RADIUS * sv.n_lights + l]));
+                    }
+                    else if (ltype == DRT_GEO_PLANE)
+                    {
+                        double u = drt_rng(rs, n_draws);
+                        double v = drt_rng(rs, n_draws);
+                        V3 lu = v3(sv.lights[LF_UX * sv.n_lights + l], sv.lights[LF_UY * sv.n_lights + l], sv.lights[LF_UZ * sv.n_lights + l]);
+                        V3 lv = v3(sv.lights[LF_VX * sv.n_lights + l], sv.lights[LF_VY * sv.n_lights + l], sv.lights[LF_VZ * sv.n_lights + l]);
+                        light_position = v_sum(v_sum(lpos, v_mul(lu, u)), v_mul(lv, v));
+                    }
+                    n_shadow += 1;
+                    bool visible = points_mutually_visible(sv, ip.position, light_position);
+                    uint64_t *lrec = vrec + REC_VERTEX_WORDS + (uint64_t)l * REC_LIGHT_WORDS;
+                    uint32_t lflags = 0;
+                    if (visible)
+                    {
+                        V3 incoming = v_normalise(v_sub(light_position, ip.position));
+                        EvalCoef e = eval_coefficients(sc, sv, ip, incoming);
+                        lflags = e.flags | FLAG_VISIBLE;
+                        double c = attenuation * (light_pdf);
+                        lrec[1] = (uint64_t)__double_as_longlong(c);
+                        store_coef(lrec + 2, e);
+                    }
+                    uint32_t em_spd = (uint32_t)sv.mats[sv.light_mat[l]].emission_spd;
+                    lrec[0] = (uint64_t)em_spd | ((uint64_t)lflags << 32);
+                }
+                /* sampled continuation, :464-472 */
+                V3 in;
+                double dir_pdf;
+                sample_direction(sc, sv, ip, rs, n_draws, in, dir_pdf);
+                EvalCoef e = eval_coefficients(sc, sv, ip, in);
+                vrec[0] = (uint64_t)ip.surface_mat | ((uint64_t)ip.incident_mat << 32);
+                vrec[1] = (uint64_t)ip.transmit_mat | ((uint64_t)e.flags << 32);
+                vrec[2] = (uint64_t)__double_as_longlong(ip.on_dot);
+                vrec[3] = (uint64_t)__double_as_longlong(dir_pdf);
+                store_coef(vrec + 4, e);
+                shaded += 1;
+                rd = in;
+                ro = ip.position;
+            }
+            depth += 1;
+            if (terminal || depth >= tp.max_depth)
+            {
+                rec[0] = (uint64_t)shaded | ((uint64_t)term << 32);
+                rec[1] = (uint64_t)term_spd;
+                alive = false;
+            }
+        }
+    }
+
+    /* statistics: wave reduction, one atomic per wave and counter */
+    uint64_t vals[5] = {n_paths, n_scans, n_shaded, n_shadow, n_draws};
+    for (int k = 0; k < 5; k += 1)
+    {
+        uint64_t v = vals[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0 && v) atomicAdd(&counters[k], (unsigned long long)v);
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* The shade + film kernel                                                                         */
+
+#define SHADE_BLOCK 256
+#define SHADE_WAVES (SHADE_BLOCK / 64)
+
+struct ShadeParams
+{
+    uint64_t n_pix;
+    uint32_t n_samples, first_sample, vertex_words, path_words;
+    uint32_t n_lights, spds_in_lds;
+};
+
+/* One BDSF sum for one wavelength: bdsf(), src/daily_ray_trace.c:215-229. `bdsf_result` is zeroed
+ * once and carried from function to function; functions whose direction test fails leave it (Q1). */
+__device__ __forceinline__ double bdsf_at_wavelength(const DevMaterial &mat, const double *__restrict__ spds, uint32_t S,
+                                                     uint32_t lam, double ir, double tr, double te, double on_dot,
+                                                     double a_in, double spec, double mn_dot, double ct_coef,
+                                                     uint32_t flags, double inv_pi)
+{
+    double bdsf_result = 0.0;
+    double reflectance = 0.0;
+    for (uint32_t i = 0; i < mat.num_bdsfs; i += 1)
+    {
+        switch (mat.bdsfs[i])
+        {
+            case DRT_BDSF_bp_diffuse_bdsf: /* src/bdsf.c:105-109 */
+            {
+                double d = mat.diffuse_spd >= 0 ? spds[(size_t)mat.diffuse_spd * S + lam] : 0.0;
+                bdsf_result = (d * inv_pi) * a_in;
+                break;
+            }
+            case DRT_BDSF_bp_glossy_bdsf: /* :111-119 */
+            {
+                double g = mat.glossy_spd >= 0 ? spds[(size_t)mat.glossy_spd * S + lam] : 0.0;
+                bdsf_result = (g * spec) * a_in;
+                break;
+            }
+            case DRT_BDSF_mirror_bdsf: /* :121-132 */
+            {
+                double m = mat.mirror_spd >= 0 ? spds[(size_t)mat.mirror_spd * S + lam] : 0.0;
+                bdsf_result = (flags & FLAG_EQR) ? m : 0.0;
+                break;
+            }
+            case DRT_BDSF_fs_conductor_bdsf: /* :134-146 */
+            {
+                if (flags & FLAG_EQR)
+                {
+                    double c2 = on_dot * on_dot;
+                    bdsf_result = conductor_reflectance(ir, tr, te, on_dot, c2, 1.0 - c2);
+                }
+                break;
+            }
+            case DRT_BDSF_fs_dielectric_reflectance_bdsf: /* :148-159 */
+            {
+                if (flags & FLAG_EQR) bdsf_result = dielectric_reflectance(ir, tr, on_dot, 1.0 - on_dot * on_dot);
+                break;
+            }
+            case DRT_BDSF_fs_dielectric_transmittance_bdsf: /* :161-172, :69-76 */
+            {
+                if (flags & FLAG_EQT) bdsf_result = 1.0 - dielectric_reflectance(ir, tr, on_dot, 1.0 - on_dot * on_dot);
+                break;
+            }
+            case DRT_BDSF_ct_conductor_bdsf: /* :174-186 */
+            {
+                double c2 = mn_dot * mn_dot;
+                bdsf_result = conductor_reflectance(ir, tr, te, mn_dot, c2, 1.0 - c2) * ct_coef;
+                break;
+            }
+            default: break;
+        }
+        reflectance = bdsf_result + reflectance;
+    }
+    return reflectance;
+}
+
+__device__ __forceinline__ double word_as_double(uint64_t w) { return __longlong_as_double((long long)w); }
+
+__global__ __launch_bounds__(SHADE_BLOCK) void drt_shade_kernel(DevScene sc, ShadeParams sp, const uint64_t *__restrict__ records,
+                                                                 double *__restrict__ film_pixels, double *__restrict__ film_avgs,
+                                                                 double *__restrict__ film_vars)
+{
+    extern __shared__ double lds_spd[];
+    const uint32_t S = sc.S;
+    const double *spds = sc.spds;
+    if (sp.spds_in_lds)
+    {
+        /* SPD block [n_spd][S] is contiguous: coalesced copy into LDS */
+        for (uint32_t k = threadIdx.x; k < sc.n_spd * S; k += SHADE_BLOCK) lds_spd[k] = sc.spds[k];
+        __syncthreads();
+        spds = lds_spd;
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t pix = (uint64_t)blockIdx.x * SHADE_WAVES + wave; /* wave-uniform */
+    if (pix >= sp.n_pix) return;
+    const double inv_pi = 1.0 / DRT_PI; /* bp_diffuse: 1.0/PI, src/bdsf.c:107 */
+    const DevMaterial *mats = sc.mats;
+
+    for (uint32_t lam0 = 0; lam0 < S; lam0 += 64)
+    {
+        const uint32_t lam = lam0 + lane;
+        const bool active = lam < S;
+        const uint32_t lam_c = active ? lam : 0;
+        double *px = film_pixels + pix * (uint64_t)(S + 1);
+        double *pa = film_avgs + pix * (uint64_t)S;
+        double *pv = film_vars + pix * (uint64_t)S;
+        double f_sum = active ? px[lam] : 0.0;
+        double f_avg = active ? pa[lam] : 0.0;
+        double f_var = active ? pv[lam] : 0.0;
+
+        for (uint32_t s = 0; s < sp.n_samples; s += 1)
+        {
+            const uint64_t *rec = records + ((uint64_t)s * sp.n_pix + pix) * (uint64_t)sp.path_words;
+            const uint64_t h0 = rec[0];
+            const uint32_t n_shaded = (uint32_t)(h0 & 0xffffffffu);
+            const uint32_t term = (uint32_t)(h0 >> 32);
+            double throughput = 1.0; /* const_spectrum(throughput, 1.0), src/daily_ray_trace.c:440 */
+            double dst = 0.0;
+            for (uint32_t v = 0; v < n_shaded; v += 1)
+            {
+                const uint64_t *vrec = rec + REC_HEADER_WORDS + (uint64_t)v * sp.vertex_words;
+                const uint64_t w0 = vrec[0], w1 = vrec[1];
+                const DevMaterial &mat = mats[(uint32_t)(w0 & 0xffffffffu)];
+                const DevMaterial &imat = mats[(uint32_t)(w0 >> 32)];
+                const DevMaterial &tmat = mats[(uint32_t)(w1 & 0xffffffffu)];
+                const uint32_t sflags = (uint32_t)(w1 >> 32);
+                const double on_dot = word_as_double(vrec[2]);
+                const double dir_pdf = word_as_double(vrec[3]);
+                const double ir = imat.refract_spd >= 0 ? spds[(size_t)imat.refract_spd * S + lam_c] : 0.0;
+                const double tr = tmat.refract_spd >= 0 ? spds[(size_t)tmat.refract_spd * S + lam_c] : 0.0;
+                const double te = tmat.extinct_spd >= 0 ? spds[(size_t)tmat.extinct_spd * S + lam_c] : 0.0;
+
+                /* direct_light_contribution, :272-332 */
+                double contribution = 0.0;
+                for (uint32_t l = 0; l < sp.n_lights; l += 1)
+                {
+                    const uint64_t *lrec = vrec + REC_VERTEX_WORDS + (uint64_t)l * REC_LIGHT_WORDS;
+                    const uint64_t lw0 = lrec[0];
+                    const uint32_t lflags = (uint32_t)(lw0 >> 32);
+                    if (!(lflags & FLAG_VISIBLE)) continue;
+                    const int32_t em_spd = (int32_t)(uint32_t)(lw0 & 0xffffffffu);
+                    const double c = word_as_double(lrec[1]);
+                    double reflectance = bdsf_at_wavelength(mat, spds, S, lam_c, ir, tr, te, on_dot, word_as_double(lrec[2]),
+                                                            word_as_double(lrec[3]), word_as_double(lrec[4]),
+                                                            word_as_double(lrec[5]), lflags, inv_pi);
+                    const double em = em_spd >= 0 ? spds[(size_t)em_spd * S + lam_c] : 0.0;
+                    contribution = contribution + reflectance; /* :323 */
+                    contribution = contribution * em;          /* :324 */
+                    contribution = contribution * c;           /* :326-327 */
+                }
+                dst = dst + throughput * contribution; /* :461-462 */
+                double reflectance = bdsf_at_wavelength(mat, spds, S, lam_c, ir, tr, te, on_dot, word_as_double(vrec[4]),
+                                                        word_as_double(vrec[5]), word_as_double(vrec[6]),
+                                                        word_as_double(vrec[7]), sflags, inv_pi);
+                reflectance = reflectance * dir_pdf;   /* :468 */
+                throughput = throughput * reflectance; /* :469 */
+            }
+            if (term == 1) /* emissive black body hit, :452-457 */
+            {
+                const int32_t em_spd = (int32_t)(uint32_t)(rec[1] & 0xffffffffu);
+                const double em = em_spd >= 0 ? spds[(size_t)em_spd * S + lam_c] : 0.0;
+                dst = dst + throughput * em;
+            }
+            const double vignette = word_as_double(rec[2]);
+            const double contribution = dst * vignette; /* :615 */
+
+            /* film update, src/daily_ray_trace.c:732-743 */
+            f_sum = f_sum + contribution;
+            double t0 = contribution - f_avg;
+            double t1 = t0;
+            t0 = t0 / (double)(sp.first_sample + s + 1);
+            f_avg = f_avg + t0;
+            t0 = contribution - f_avg;
+            t0 = t1 * t0;
+            f_var = f_var + t0;
+        }
+        if (active)
+        {
+            px[lam] = f_sum;
+            pa[lam] = f_avg;
+            pv[lam] = f_var;
+        }
+        if (lam0 == 0 && lane == 0) px[S] += (double)sp.n_samples * 1.0; /* filter sum: += 1.0 per sample, :733 */
+    }
+}
+
+/* spectrum_to_xyz over the film (src/daily_ray_trace.c:15-23, src/spectrum.c:49-70): one thread per
+ * pixel so the sums run in the reference's order. */
+__global__ void drt_film_xyz_kernel(DevScene sc, uint32_t cmf_rw, uint32_t cmf_x, uint32_t cmf_y, uint32_t cmf_z, double interval,
+                                    uint64_t n_pix, const double *__restrict__ film_pixels, double *__restrict__ xyz)
+{
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pix) return;
+    const uint32_t S = sc.S;
+    const double *rw = sc.spds + (size_t)cmf_rw * S, *cx = sc.spds + (size_t)cmf_x * S;
+    const double *cy = sc.spds + (size_t)cmf_y * S, *cz = sc.spds + (size_t)cmf_z * S;
+    const double *px = film_pixels + p * (uint64_t)(S + 1);
+    double f = px[S];
+    double n = 0.0;
+    for (uint32_t i = 0; i < S; i += 1) n += (cy[i] * rw[i]);
+    n *= interval;
+    double X = 0.0, Y = 0.0, Z = 0.0;
+    for (uint32_t i = 0; i < S; i += 1)
+    {
+        double v = px[i] / f;
+        X += (cx[i] * v * rw[i]);
+        Y += (cy[i] * v * rw[i]);
+        Z += (cz[i] * v * rw[i]);
+    }
+    xyz[3 * p + 0] = X * (interval / n);
+    xyz[3 * p + 1] = Y * (interval / n);
+    xyz[3 * p + 2] = Z * (interval / n);
+}
+
+/* arithmetic self-test (see drt_selftest_arith in include/drt_hip.h) */
+__global__ void drt_selftest_kernel(int op, const double *a, const double *b, double *out, uint64_t n)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    switch (op)
+    {
+        case 0: out[i] = __builtin_sqrt(a[i]); break;
+        case 1: out[i] = a[i] / b[i]; break;
+        case 2:
+        {
+            double s, c;
+            drt_sincos(a[i], s, c);
+            out[2 * i] = s;
+            out[2 * i + 1] = c;
+            break;
+        }
+        case 3: out[i] = pow(a[i], b[i]); break;
+        case 4:
+        {
+            uint64_t key = (uint64_t)__double_as_longlong(a[i]);
+            uint64_t rs = drt_splitmix64(key);
+            uint32_t draws = 0;
+            double v = 0.0;
+            for (int k = 0; k < 4; k += 1) v = drt_rng(rs, draws);
+            out[i] = v;
+            break;
+        }
+        default: out[i] = 0.0; break;
+    }
+}

@@ -1,0 +1,620 @@
+/*
+ * drt_launcher.hip -- the C-ABI of include/drt_hip.h: scene upload (AoS boundary structs -> SoA
+ * device tables), film ownership, batch scheduling of the trace and shade kernels on one HIP
+ * stream, HIP-event timing, statistics. gfx950 only; there is no CPU path in this library.
+ */
+#include "drt_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                      \
+    do                                                                                                     \
+    {                                                                                                      \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return fail(-100 - (int)e_, "%s: %s", #expr, hipGetErrorString(e_));         \
+    } while (0)
+
+struct drt_context
+{
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    drt_params  params{};
+    DevScene    dsc{};
+    DevCamera   dcam{};
+    uint32_t    cmf_rw = 0, cmf_x = 0, cmf_y = 0, cmf_z = 0;
+    double      interval = 0.0;
+
+    std::vector<void *> allocations; /* scene tables */
+    double *d_pixels = nullptr, *d_avgs = nullptr, *d_vars = nullptr;
+    bool    own_film = false;
+    uint64_t *d_records = nullptr;
+    uint32_t  batch_spp = 1;
+    uint32_t  vertex_words = 0, path_words = 0;
+    int32_t  *d_hits = nullptr;
+    uint64_t  hits_capacity = 0; /* in paths */
+    uint32_t  hits_samples = 0;
+    unsigned long long *d_counters = nullptr; /* DRT_NUM_COUNTERS stats + 1 work counter */
+    double   *d_xyz = nullptr;
+
+    bool   scene_in_lds = true, spds_in_lds = true;
+    size_t trace_lds = 0, shade_lds = 0;
+    int    trace_grid_cap = 0;
+    uint64_t n_pix = 0;
+
+    std::vector<hipEvent_t> ev; /* triples: trace start, trace end / shade start, shade end */
+    size_t ev_used = 0;
+    double trace_ms = 0.0, shade_ms = 0.0;
+    drt_stats host_stats{};
+};
+
+static size_t trace_lds_bytes(uint32_t n_surf, uint32_t n_lights, uint32_t n_mat)
+{
+    size_t b = (size_t)SF_COUNT * n_surf * 8 + (size_t)LF_COUNT * n_lights * 8;
+    b += ((size_t)(2 * n_surf + 2 * n_lights) * 4 + 7) & ~(size_t)7;
+    b += (size_t)n_mat * sizeof(DevMaterial);
+    return b;
+}
+
+template <typename T>
+static int upload(drt_context *ctx, const std::vector<T> &host, const T **dev)
+{
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(host.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&p, bytes));
+    ctx->allocations.push_back(p);
+    if (!host.empty()) HIP_TRY(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = (const T *)p;
+    return 0;
+}
+
+static V3 hv(const double a[3]) { V3 r; r.x = a[0]; r.y = a[1]; r.z = a[2]; return r; }
+
+/* host-side twins of the device vector ops used for per-surface constants (same IEEE ops) */
+static double h_dot(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static double h_length(const double a[3]) { return std::sqrt(h_dot(a, a)); }
+
+static int build_device_scene(drt_context *ctx, const drt_scene *scene)
+{
+    const uint32_t S = scene->num_wavelengths;
+    const uint32_t n_surf = scene->num_surfaces;
+    if (S == 0 || scene->num_spds == 0 || !scene->spds) return fail(-2, "scene has no spectral tables");
+    if (scene->base_material >= scene->num_materials || scene->escape_material >= scene->num_materials)
+        return fail(-2, "base/escape material index out of range");
+
+    DevScene &d = ctx->dsc;
+    d.n_surf = n_surf;
+    d.n_mat = scene->num_materials;
+    d.S = S;
+    d.n_spd = scene->num_spds;
+    d.base_mat = scene->base_material;
+    d.escape_mat = scene->escape_material;
+    /* value_at_wl(., trans_wl = 630), src/spectrum.c:150-162 and src/daily_ray_trace.c:381 */
+    d.trans_wl = 630.0;
+    d.trans_i0 = (uint32_t)((d.trans_wl - scene->min_wavelength) / scene->wavelength_interval);
+    if (d.trans_i0 + 1 >= S) return fail(-2, "wavelength grid does not bracket trans_wl = 630 nm");
+    d.trans_w0 = scene->min_wavelength + d.trans_i0 * scene->wavelength_interval;
+    d.trans_w1 = scene->min_wavelength + (d.trans_i0 + 1) * scene->wavelength_interval;
+
+    std::vector<double> surf((size_t)SF_COUNT * n_surf, 0.0);
+    std::vector<uint32_t> stype(n_surf), smat(n_surf);
+    std::vector<double> lights;
+    std::vector<uint32_t> ltype, lmat;
+    std::vector<uint32_t> light_surfaces;
+    for (uint32_t i = 0; i < n_surf; i += 1)
+    {
+        const drt_surface &s = scene->surfaces[i];
+        if (s.material >= scene->num_materials) return fail(-2, "surface %u: material index out of range", i);
+        stype[i] = s.type;
+        smat[i] = s.material;
+        surf[(size_t)SF_PX * n_surf + i] = s.position[0];
+        surf[(size_t)SF_PY * n_surf + i] = s.position[1];
+        surf[(size_t)SF_PZ * n_surf + i] = s.position[2];
+        surf[(size_t)SF_RADIUS * n_surf + i] = s.radius;
+        if (s.type == DRT_GEO_PLANE)
+        {
+            /* |u|, |v|, u/|u|, v/|v|: what line_plane_intersection recomputes per ray (src/geometry.c:166-170) */
+            double ul = h_length(s.u), vl = h_length(s.v);
+            surf[(size_t)SF_NX * n_surf + i] = s.normal[0];
+            surf[(size_t)SF_NY * n_surf + i] = s.normal[1];
+            surf[(size_t)SF_NZ * n_surf + i] = s.normal[2];
+            for (int k = 0; k < 3; k += 1)
+            {
+                surf[(size_t)(SF_UNX + k) * n_surf + i] = s.u[k] / ul;
+                surf[(size_t)(SF_VNX + k) * n_surf + i] = s.v[k] / vl;
+            }
+            surf[(size_t)SF_ULEN * n_surf + i] = ul;
+            surf[(size_t)SF_VLEN * n_surf + i] = vl;
+        }
+        if (scene->materials[s.material].is_emissive) light_surfaces.push_back(i);
+    }
+    const uint32_t n_lights = (uint32_t)light_surfaces.size();
+    d.n_lights = n_lights;
+    lights.assign((size_t)LF_COUNT * std::max<uint32_t>(n_lights, 1), 0.0);
+    ltype.resize(n_lights);
+    lmat.resize(n_lights);
+    for (uint32_t l = 0; l < n_lights; l += 1)
+    {
+        const drt_surface &s = scene->surfaces[light_surfaces[l]];
+        ltype[l] = s.type;
+        lmat[l] = s.material;
+        for (int k = 0; k < 3; k += 1)
+        {
+            lights[(size_t)(LF_PX + k) * n_lights + l] = s.position[k];
+            lights[(size_t)(LF_UX + k) * n_lights + l] = s.u[k];
+            lights[(size_t)(LF_VX + k) * n_lights + l] = s.v[k];
+        }
+        lights[(size_t)LF_RADIUS * n_lights + l] = s.radius;
+        double pdf = 1.0; /* src/daily_ray_trace.c:292, :304, :314 */
+        if (s.type == DRT_GEO_SPHERE) pdf = ((4.0 * DRT_PI) * s.radius) * s.radius;
+        else if (s.type == DRT_GEO_PLANE)
+        {
+            double c[3] = {s.u[1] * s.v[2] - s.u[2] * s.v[1], s.u[2] * s.v[0] - s.u[0] * s.v[2], s.u[0] * s.v[1] - s.u[1] * s.v[0]};
+            pdf = h_length(c);
+        }
+        lights[(size_t)LF_PDF * n_lights + l] = pdf;
+    }
+
+    std::vector<DevMaterial> mats(scene->num_materials);
+    for (uint32_t i = 0; i < scene->num_materials; i += 1)
+    {
+        const drt_material &m = scene->materials[i];
+        DevMaterial &dm = mats[i];
+        memset(&dm, 0, sizeof(dm));
+        dm.is_black_body = m.is_black_body;
+        dm.is_emissive = m.is_emissive;
+        dm.num_bdsfs = std::min<uint32_t>(m.num_bdsfs, DRT_MAX_BDSFS);
+        dm.dir_func = m.dir_func;
+        const int32_t idx[6] = {m.emission_spd, m.diffuse_spd, m.glossy_spd, m.mirror_spd, m.refract_spd, m.extinct_spd};
+        for (int k = 0; k < 6; k += 1)
+            if (idx[k] >= (int32_t)scene->num_spds) return fail(-2, "material %u: SPD index out of range", i);
+        dm.emission_spd = m.emission_spd; dm.diffuse_spd = m.diffuse_spd; dm.glossy_spd = m.glossy_spd;
+        dm.mirror_spd = m.mirror_spd; dm.refract_spd = m.refract_spd; dm.extinct_spd = m.extinct_spd;
+        dm.shininess = m.shininess;
+        dm.roughness = m.roughness;
+        if (m.refract_spd >= 0)
+        {
+            dm.refract_i0 = scene->spds[(size_t)m.refract_spd * S + d.trans_i0];
+            dm.refract_i1 = scene->spds[(size_t)m.refract_spd * S + d.trans_i0 + 1];
+        }
+        for (uint32_t j = 0; j < dm.num_bdsfs; j += 1)
+        {
+            uint32_t b = m.bdsfs[j];
+            if (b >= DRT_NUM_BDSFS) return fail(-2, "material %u: unknown bdsf id %u", i, b);
+            dm.bdsfs[j] = b;
+            if (b == DRT_BDSF_bp_glossy_bdsf) dm.needs |= NEED_GLOSSY;
+            if (b == DRT_BDSF_mirror_bdsf || b == DRT_BDSF_fs_conductor_bdsf || b == DRT_BDSF_fs_dielectric_reflectance_bdsf) dm.needs |= NEED_EQR;
+            if (b == DRT_BDSF_fs_dielectric_transmittance_bdsf) dm.needs |= NEED_EQT;
+            if (b == DRT_BDSF_ct_conductor_bdsf) dm.needs |= NEED_CT;
+        }
+        if (!m.is_black_body && dm.dir_func >= DRT_NUM_DIRFS) return fail(-2, "material %u: unknown dir_func id %u", i, dm.dir_func);
+    }
+    std::vector<double> spds(scene->spds, scene->spds + (size_t)scene->num_spds * S);
+
+    int rc;
+    if ((rc = upload(ctx, surf, &d.surf))) return rc;
+    if ((rc = upload(ctx, stype, &d.surf_type))) return rc;
+    if ((rc = upload(ctx, smat, &d.surf_mat))) return rc;
+    if ((rc = upload(ctx, lights, &d.lights))) return rc;
+    if ((rc = upload(ctx, ltype, &d.light_type))) return rc;
+    if ((rc = upload(ctx, lmat, &d.light_mat))) return rc;
+    if ((rc = upload(ctx, mats, &d.mats))) return rc;
+    if ((rc = upload(ctx, spds, &d.spds))) return rc;
+    d.inv_pi_diffuse = nullptr;
+
+    ctx->cmf_rw = scene->cmf_rw; ctx->cmf_x = scene->cmf_x; ctx->cmf_y = scene->cmf_y; ctx->cmf_z = scene->cmf_z;
+    ctx->interval = scene->wavelength_interval;
+    if (std::max(std::max(ctx->cmf_rw, ctx->cmf_x), std::max(ctx->cmf_y, ctx->cmf_z)) >= scene->num_spds)
+        return fail(-2, "colour-matching SPD index out of range");
+
+    /* LDS budgets: keep the scene in LDS when it leaves room for >= 2 workgroups per CU */
+    ctx->trace_lds = trace_lds_bytes(n_surf, n_lights, scene->num_materials);
+    ctx->scene_in_lds = ctx->trace_lds <= 64 * 1024;
+    if (!ctx->scene_in_lds) ctx->trace_lds = 0;
+    ctx->shade_lds = (size_t)scene->num_spds * S * 8;
+    ctx->spds_in_lds = ctx->shade_lds <= 64 * 1024;
+    if (!ctx->spds_in_lds) ctx->shade_lds = 0;
+    return 0;
+}
+
+extern "C" const char *drt_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int drt_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(-1, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camera *camera, const drt_params *params)
+{
+    if (!scene || !camera || !params) return fail(-1, "null argument");
+    if (params->tile_w == 0 || params->tile_h == 0 || params->max_depth == 0) return fail(-1, "empty tile or zero depth");
+    ctx->params = *params;
+    if (ctx->params.row_stride == 0) ctx->params.row_stride = 1;
+    ctx->device = params->device;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    int rc = build_device_scene(ctx, scene);
+    if (rc) return rc;
+
+    DevCamera &c = ctx->dcam;
+    c.forward = hv(camera->forward); c.right = hv(camera->right); c.up = hv(camera->up);
+    c.aperture_position = hv(camera->aperture_position); c.film_bottom_left = hv(camera->film_bottom_left);
+    c.aperture_radius = camera->aperture_radius; c.focal_depth = camera->focal_depth;
+    c.pixel_width = camera->pixel_width; c.pixel_height = camera->pixel_height;
+
+    const uint32_t S = scene->num_wavelengths;
+    ctx->n_pix = (uint64_t)params->tile_w * params->tile_h;
+    ctx->vertex_words = REC_VERTEX_WORDS + REC_LIGHT_WORDS * ctx->dsc.n_lights;
+    ctx->path_words = REC_HEADER_WORDS + ctx->vertex_words * params->max_depth;
+
+    /* batch: enough paths in flight to fill the chip many times over, bounded record memory */
+    uint32_t batch = params->batch_spp;
+    if (batch == 0)
+    {
+        uint64_t target_paths = 4ull << 20;
+        batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, target_paths / std::max<uint64_t>(ctx->n_pix, 1)));
+    }
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    size_t film_bytes = (size_t)ctx->n_pix * (3 * (size_t)S + 1) * 8;
+    while (batch > 1 && (size_t)ctx->n_pix * batch * ctx->path_words * 8 + film_bytes > free_b / 2) batch /= 2;
+    ctx->batch_spp = batch;
+    size_t rec_bytes = (size_t)ctx->n_pix * batch * ctx->path_words * 8;
+    if (rec_bytes + film_bytes > free_b) return fail(-3, "not enough device memory: need %zu bytes", rec_bytes + film_bytes);
+    HIP_TRY(hipMalloc((void **)&ctx->d_records, rec_bytes));
+
+    HIP_TRY(hipMalloc((void **)&ctx->d_pixels, (size_t)ctx->n_pix * (S + 1) * 8));
+    HIP_TRY(hipMalloc((void **)&ctx->d_avgs, (size_t)ctx->n_pix * S * 8));
+    HIP_TRY(hipMalloc((void **)&ctx->d_vars, (size_t)ctx->n_pix * S * 8));
+    ctx->own_film = true;
+    HIP_TRY(hipMemsetAsync(ctx->d_pixels, 0, (size_t)ctx->n_pix * (S + 1) * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_avgs, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_vars, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
+    HIP_TRY(hipMalloc((void **)&ctx->d_counters, (DRT_NUM_COUNTERS + 1) * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 1) * sizeof(unsigned long long), ctx->stream));
+
+    /* persistent trace grid: as many workgroups as the chip keeps resident */
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    int per_cu = 0;
+    if (ctx->scene_in_lds)
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, drt_trace_kernel<true>, TRACE_BLOCK, ctx->trace_lds));
+    else
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, drt_trace_kernel<false>, TRACE_BLOCK, 0));
+    if (per_cu < 1) per_cu = 1;
+    ctx->trace_grid_cap = prop.multiProcessorCount * per_cu;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" drt_context *drt_create(const drt_scene *scene, const drt_camera *camera, const drt_params *params)
+{
+    g_last_error.clear();
+    drt_context *ctx = new drt_context();
+    int rc = create_impl(ctx, scene, camera, params);
+    if (rc != 0)
+    {
+        std::string keep = g_last_error;
+        drt_destroy(ctx);
+        g_last_error = keep;
+        return nullptr;
+    }
+    return ctx;
+}
+
+extern "C" void drt_destroy(drt_context *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (void *p : ctx->allocations) (void)hipFree(p);
+    if (ctx->own_film)
+    {
+        (void)hipFree(ctx->d_pixels);
+        (void)hipFree(ctx->d_avgs);
+        (void)hipFree(ctx->d_vars);
+    }
+    (void)hipFree(ctx->d_records);
+    (void)hipFree(ctx->d_hits);
+    (void)hipFree(ctx->d_counters);
+    (void)hipFree(ctx->d_xyz);
+    for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" int drt_bind_film(drt_context *ctx, void *d_pixels, void *d_avgs, void *d_vars)
+{
+    if (!ctx || !d_pixels || !d_avgs || !d_vars) return fail(-1, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_film)
+    {
+        (void)hipFree(ctx->d_pixels);
+        (void)hipFree(ctx->d_avgs);
+        (void)hipFree(ctx->d_vars);
+        ctx->own_film = false;
+    }
+    ctx->d_pixels = (double *)d_pixels;
+    ctx->d_avgs = (double *)d_avgs;
+    ctx->d_vars = (double *)d_vars;
+    return 0;
+}
+
+extern "C" int drt_set_stream(drt_context *ctx, void *hip_stream)
+{
+    if (!ctx) return fail(-1, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return 0;
+}
+
+static int next_events(drt_context *ctx, hipEvent_t out[3])
+{
+    while (ctx->ev.size() < ctx->ev_used + 3)
+    {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        ctx->ev.push_back(e);
+    }
+    for (int k = 0; k < 3; k += 1) out[k] = ctx->ev[ctx->ev_used + k];
+    ctx->ev_used += 3;
+    return 0;
+}
+
+/* fold finished event triples into trace_ms / shade_ms (stream must be idle) */
+static int collect_timings(drt_context *ctx)
+{
+    for (size_t k = 0; k + 3 <= ctx->ev_used; k += 3)
+    {
+        float a = 0.f, b = 0.f;
+        HIP_TRY(hipEventElapsedTime(&a, ctx->ev[k], ctx->ev[k + 1]));
+        HIP_TRY(hipEventElapsedTime(&b, ctx->ev[k + 1], ctx->ev[k + 2]));
+        ctx->trace_ms += a;
+        ctx->shade_ms += b;
+    }
+    ctx->ev_used = 0;
+    return 0;
+}
+
+extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_samples)
+{
+    if (!ctx) return fail(-1, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const drt_params &p = ctx->params;
+    if (p.flags & DRT_FLAG_RECORD_HITS)
+    {
+        uint64_t need = ctx->n_pix * (uint64_t)num_samples;
+        if (need > ctx->hits_capacity)
+        {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->d_hits);
+            ctx->d_hits = nullptr;
+            HIP_TRY(hipMalloc((void **)&ctx->d_hits, std::max<uint64_t>(need, 1) * p.max_depth * sizeof(int32_t)));
+            ctx->hits_capacity = need;
+        }
+        ctx->hits_samples = num_samples;
+    }
+    /* keep the number of pending timing events bounded */
+    if (ctx->ev_used >= 3 * 256)
+    {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        int rc = collect_timings(ctx);
+        if (rc) return rc;
+    }
+    for (uint32_t done = 0; done < num_samples; done += ctx->batch_spp)
+    {
+        uint32_t n = std::min(ctx->batch_spp, num_samples - done);
+        TraceParams tp{};
+        tp.width = p.width; tp.height = p.height; tp.x0 = p.x0; tp.y0 = p.y0;
+        tp.tile_w = p.tile_w; tp.tile_h = p.tile_h; tp.row_stride = p.row_stride;
+        tp.first_sample = first_sample + done;
+        tp.n_samples = n;
+        tp.max_depth = p.max_depth;
+        tp.pixel_scheme = p.pixel_scheme;
+        tp.record_hits = (p.flags & DRT_FLAG_RECORD_HITS) ? 1u : 0u;
+        tp.seed = p.seed;
+        tp.n_pix = ctx->n_pix;
+        tp.n_paths = ctx->n_pix * n;
+        tp.vertex_words = ctx->vertex_words;
+        tp.path_words = ctx->path_words;
+        tp.hits_sample_offset = done;
+
+        hipEvent_t ev[3];
+        int rc = next_events(ctx, ev);
+        if (rc) return rc;
+        unsigned long long *work = ctx->d_counters + DRT_NUM_COUNTERS;
+        HIP_TRY(hipMemsetAsync(work, 0, sizeof(unsigned long long), ctx->stream));
+        uint64_t blocks_needed = (tp.n_paths + TRACE_BLOCK - 1) / TRACE_BLOCK;
+        uint32_t grid = (uint32_t)std::min<uint64_t>(blocks_needed, (uint64_t)ctx->trace_grid_cap);
+        HIP_TRY(hipEventRecord(ev[0], ctx->stream));
+        if (ctx->scene_in_lds)
+            hipLaunchKernelGGL(drt_trace_kernel<true>, dim3(grid), dim3(TRACE_BLOCK), ctx->trace_lds, ctx->stream, ctx->dsc,
+                               ctx->dcam, tp, ctx->d_records, ctx->d_hits, ctx->d_counters, work);
+        else
+            hipLaunchKernelGGL(drt_trace_kernel<false>, dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->dsc, ctx->dcam, tp,
+                               ctx->d_records, ctx->d_hits, ctx->d_counters, work);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev[1], ctx->stream));
+
+        ShadeParams sp{};
+        sp.n_pix = ctx->n_pix;
+        sp.n_samples = n;
+        sp.first_sample = first_sample + done;
+        sp.vertex_words = ctx->vertex_words;
+        sp.path_words = ctx->path_words;
+        sp.n_lights = ctx->dsc.n_lights;
+        sp.spds_in_lds = ctx->spds_in_lds ? 1u : 0u;
+        uint32_t sgrid = (uint32_t)((ctx->n_pix + SHADE_WAVES - 1) / SHADE_WAVES);
+        hipLaunchKernelGGL(drt_shade_kernel, dim3(sgrid), dim3(SHADE_BLOCK), ctx->shade_lds, ctx->stream, ctx->dsc, sp,
+                           ctx->d_records, ctx->d_pixels, ctx->d_avgs, ctx->d_vars);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev[2], ctx->stream));
+    }
+    return 0;
+}
+
+extern "C" int drt_synchronize(drt_context *ctx)
+{
+    if (!ctx) return fail(-1, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return collect_timings(ctx);
+}
+
+extern "C" int drt_reset_film(drt_context *ctx)
+{
+    if (!ctx) return fail(-1, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = drt_synchronize(ctx);
+    if (rc) return rc;
+    const size_t S = ctx->dsc.S;
+    HIP_TRY(hipMemsetAsync(ctx->d_pixels, 0, (size_t)ctx->n_pix * (S + 1) * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_avgs, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_vars, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 1) * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->trace_ms = ctx->shade_ms = 0.0;
+    return 0;
+}
+
+extern "C" int drt_film_device_ptrs(drt_context *ctx, void **d_pixels, void **d_avgs, void **d_vars)
+{
+    if (!ctx) return fail(-1, "null context");
+    if (d_pixels) *d_pixels = ctx->d_pixels;
+    if (d_avgs) *d_avgs = ctx->d_avgs;
+    if (d_vars) *d_vars = ctx->d_vars;
+    return 0;
+}
+
+extern "C" int drt_read_film(drt_context *ctx, double *pixels, double *avgs, double *vars)
+{
+    if (!ctx) return fail(-1, "null context");
+    int rc = drt_synchronize(ctx);
+    if (rc) return rc;
+    const size_t S = ctx->dsc.S;
+    if (pixels) HIP_TRY(hipMemcpy(pixels, ctx->d_pixels, (size_t)ctx->n_pix * (S + 1) * 8, hipMemcpyDeviceToHost));
+    if (avgs) HIP_TRY(hipMemcpy(avgs, ctx->d_avgs, (size_t)ctx->n_pix * S * 8, hipMemcpyDeviceToHost));
+    if (vars) HIP_TRY(hipMemcpy(vars, ctx->d_vars, (size_t)ctx->n_pix * S * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int drt_read_xyz(drt_context *ctx, double *xyz)
+{
+    if (!ctx || !xyz) return fail(-1, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->d_xyz) HIP_TRY(hipMalloc((void **)&ctx->d_xyz, (size_t)ctx->n_pix * 3 * 8));
+    uint32_t grid = (uint32_t)((ctx->n_pix + 255) / 256);
+    hipLaunchKernelGGL(drt_film_xyz_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->dsc, ctx->cmf_rw, ctx->cmf_x, ctx->cmf_y,
+                       ctx->cmf_z, ctx->interval, ctx->n_pix, ctx->d_pixels, ctx->d_xyz);
+    HIP_TRY(hipGetLastError());
+    int rc = drt_synchronize(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(xyz, ctx->d_xyz, (size_t)ctx->n_pix * 3 * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int drt_read_hit_indices(drt_context *ctx, int32_t *dst, uint64_t capacity_paths)
+{
+    if (!ctx || !dst) return fail(-1, "null argument");
+    if (!(ctx->params.flags & DRT_FLAG_RECORD_HITS) || !ctx->d_hits) return fail(-4, "hit recording is off (DRT_FLAG_RECORD_HITS)");
+    int rc = drt_synchronize(ctx);
+    if (rc) return rc;
+    uint64_t n = std::min<uint64_t>(capacity_paths, ctx->n_pix * (uint64_t)ctx->hits_samples);
+    HIP_TRY(hipMemcpy(dst, ctx->d_hits, n * ctx->params.max_depth * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int drt_get_stats(drt_context *ctx, drt_stats *out)
+{
+    if (!ctx || !out) return fail(-1, "null argument");
+    int rc = drt_synchronize(ctx);
+    if (rc) return rc;
+    unsigned long long c[DRT_NUM_COUNTERS];
+    HIP_TRY(hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(*out));
+    out->paths = c[0];
+    out->closest_hit_scans = c[1];
+    out->shaded_vertices = c[2];
+    out->shadow_scans = c[3];
+    out->rng_draws = c[4];
+    out->trace_ms = ctx->trace_ms;
+    out->shade_ms = ctx->shade_ms;
+    out->total_ms = ctx->trace_ms + ctx->shade_ms;
+    return 0;
+}
+
+extern "C" int drt_render_tile(const drt_scene *scene, const drt_camera *camera, const drt_params *params,
+                               double *dst_pixels, double *dst_avgs, double *dst_vars, drt_stats *stats)
+{
+    g_last_error.clear();
+    if (!dst_pixels || !dst_avgs || !dst_vars) return fail(-1, "null film buffer");
+    drt_context *ctx = drt_create(scene, camera, params);
+    if (!ctx) return -1;
+    int rc = 0;
+    const size_t S = ctx->dsc.S;
+    do
+    {
+        /* accumulate INTO the caller's buffers: start from their contents */
+        hipError_t e;
+        if ((e = hipMemcpy(ctx->d_pixels, dst_pixels, (size_t)ctx->n_pix * (S + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(ctx->d_avgs, dst_avgs, (size_t)ctx->n_pix * S * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(ctx->d_vars, dst_vars, (size_t)ctx->n_pix * S * 8, hipMemcpyHostToDevice)) != hipSuccess)
+        {
+            rc = fail(-100 - (int)e, "film upload: %s", hipGetErrorString(e));
+            break;
+        }
+        if ((rc = drt_render(ctx, params->first_sample, params->spp))) break;
+        if ((rc = drt_read_film(ctx, dst_pixels, dst_avgs, dst_vars))) break;
+        if (stats && (rc = drt_get_stats(ctx, stats))) break;
+    } while (0);
+    std::string keep = g_last_error;
+    drt_destroy(ctx);
+    g_last_error = keep;
+    return rc;
+}
+
+extern "C" int drt_selftest_arith(int device, int op, const double *a, const double *b, double *out, uint64_t n)
+{
+    g_last_error.clear();
+    HIP_TRY(hipSetDevice(device));
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    size_t out_n = (op == 2) ? 2 * n : n;
+    HIP_TRY(hipMalloc((void **)&da, std::max<uint64_t>(n, 1) * 8));
+    HIP_TRY(hipMalloc((void **)&db, std::max<uint64_t>(n, 1) * 8));
+    HIP_TRY(hipMalloc((void **)&dout, std::max<size_t>(out_n, 1) * 8));
+    HIP_TRY(hipMemcpy(da, a, n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db, b, n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(drt_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, da, db, dout, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, out_n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(da);
+    (void)hipFree(db);
+    (void)hipFree(dout);
+    return 0;
+}
