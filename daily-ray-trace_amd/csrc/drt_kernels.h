@@ -61,6 +61,7 @@ struct DevMaterial
     double   shininess, roughness;
     double   refract_i0, refract_i1; /* refract_spd at the two samples around trans_wl (value_at_wl) */
     uint32_t bdsfs[DRT_MAX_BDSFS];
+    uint64_t bdsf_packed; /* bdsfs[] as 4-bit fields */
 };
 
 struct DevScene
@@ -86,22 +87,28 @@ struct DevCamera
 };
 
 /* ---------------------------------------------------------------------------------------------- */
-/* Vertex records (trace -> shade). All 8-byte words.                                              */
+/* Vertex records (trace -> shade). All 8-byte words; self-contained, so the shade kernel never  */
+/* looks a material up: the trace kernel resolves it into a packed BDSF list + SPD indices.        */
+/* Records of one pixel's samples are contiguous: path slot = pixel * batch + sample_in_batch.     */
 /*                                                                                                  */
-/*  path header (8 words):  w0 = n_shaded | term<<32   (term: 0 none/escape, 1 emissive hit)       */
-/*                          w1 = emission SPD index of the emissive hit                            */
-/*                          w2 = vignette (double)                                                 */
-/*  vertex fixed part (8):  w0 = surface material | incident material<<32                          */
-/*                          w1 = transmit material | sampled-direction flags<<32                   */
-/*                          w2 = on_dot, w3 = 1/pdf of the sampled direction                       */
-/*                          w4..w7 = |n.in|, glossy pow term, |n.m|, GGX coefficient  (sampled dir) */
-/*  per light (8):          w0 = emission SPD index | flags<<32, w1 = atten * area                 */
-/*                          w2..w5 = the same four coefficients for the light direction            */
+/*  path header (2 words, own array):                                                              */
+/*     w0 = n_shaded (bits 0-15) | term (16-23: 0 none/escape, 1 emissive hit) | emission SPD (32-47) */
+/*     w1 = vignette (double)                                                                      */
+/*  vertex fixed part (10 words):                                                                  */
+/*     w0 = BDSF list, 4 bits per entry (the material's bdsfs[] in order)                          */
+/*     w1 = num_bdsfs (0-7) | sampled-direction flags (8-15) | diffuse SPD (16-31) | glossy SPD (32-47) | mirror SPD (48-63) */
+/*     w2 = incident refract SPD (0-15) | transmit refract SPD (16-31) | transmit extinct SPD (32-47) */
+/*     w3 = on_dot, w4 = 1/pdf of the sampled direction                                            */
+/*     w5..w8 = |n.in|, glossy pow term, |n.m|, GGX coefficient (sampled direction), w9 unused      */
+/*  per light (6 words):                                                                           */
+/*     w0 = emission SPD (0-15) | flags (16-23), w1 = atten * area, w2..w5 = the four coefficients  */
 /*  flags: bit0 in == mirror direction, bit1 in == refracted direction, bit2 light visible         */
+/*  SPD index 0xFFFF = no spectrum (reads as zeros).                                               */
 
-#define REC_HEADER_WORDS 8
-#define REC_VERTEX_WORDS 8
-#define REC_LIGHT_WORDS 8
+#define REC_HEADER_WORDS 2
+#define REC_VERTEX_WORDS 10
+#define REC_LIGHT_WORDS 6
+#define REC_NO_SPD 0xFFFFu
 #define FLAG_EQR 1u
 #define FLAG_EQT 2u
 #define FLAG_VISIBLE 4u
@@ -112,8 +119,8 @@ struct TraceParams
     uint32_t first_sample, n_samples, max_depth, pixel_scheme, record_hits;
     uint64_t seed;
     uint64_t n_pix, n_paths;
-    uint32_t vertex_words, path_words; /* record strides in 8-byte words */
-    uint32_t hits_sample_offset, pad;
+    uint32_t vertex_words, path_words; /* record strides in 8-byte words (path_words = max_depth * vertex_words) */
+    uint32_t hits_sample_offset, batch;  /* batch = sample slots per pixel in the record arrays */
 };
 
 struct EvalCoef
@@ -414,8 +421,8 @@ __device__ __forceinline__ void camera_ray(const DevCamera &cam, uint32_t scheme
 
 template <bool SCENE_IN_LDS>
 __global__ __launch_bounds__(TRACE_BLOCK) void drt_trace_kernel(DevScene sc, DevCamera cam, TraceParams tp,
-                                                                 uint64_t *__restrict__ records, int32_t *__restrict__ hits,
-                                                                 unsigned long long *__restrict__ counters,
+                                                                 uint64_t *__restrict__ records, uint64_t *__restrict__ headers,
+                                                                 int32_t *__restrict__ hits, unsigned long long *__restrict__ counters,
                                                                  unsigned long long *__restrict__ work_counter)
 {
     extern __shared__ double lds_raw[];
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void drt_trace_kernel(DevScene sc, Dev
     uint64_t pid = 0, rs = 1;
     uint32_t depth = 0, shaded = 0;
     V3 ro = v3(0, 0, 0), rd = v3(0, 0, 0);
-    uint64_t *rec = nullptr;
+    uint64_t *rec = nullptr, *hdr = nullptr;
 
     for (;;)
     {
@@ -550,9 +557,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) void drt_trace_kernel(DevScene sc, Dev
                 camera_ray(cam, tp.pixel_scheme, x, y, rs, n_draws, ro, rd);
                 depth = 0;
                 shaded = 0;
-                rec = records + pid * (uint64_t)tp.path_words;
+                uint64_t slot = q * (uint64_t)tp.batch + s_local;
+                rec = records + slot * (uint64_t)tp.path_words;
+                hdr = headers + slot * REC_HEADER_WORDS;
                 /* vignette: dot(ray_direction, forward) of the PRIMARY ray, src/daily_ray_trace.c:614 */
-                rec[2] = (uint64_t)__double_as_longlong(v_dot(rd, cam.forward) * 1.0);
+                hdr[1] = (uint64_t)__double_as_longlong(v_dot(rd, cam.forward) * 1.0);
                 n_paths += 1;
                 if (tp.record_hits)
                 {
@@ -582,7 +591,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void drt_trace_kernel(DevScene sc, Dev
             }
             else
             {
-                uint64_t *vrec = rec + REC_HEADER_WORDS + (uint64_t)shaded * tp.vertex_words;
+                uint64_t *vrec = rec + (uint64_t)shaded * tp.vertex_words;
                 /* direct_light_contribution, :272-332 -- light samples are drawn before the shadow test */
                 n_shaded += 1;
                 for (uint32_t l = 0; l < sv.n_lights; l += 1)
@@ -629,19 +638,23 @@ __global__ __launch_bounds__(TRACE_BLOCK) void drt_trace_kernel(DevScene sc, Dev
                         lrec[1] = (uint64_t)__double_as_longlong(c);
                         store_coef(lrec + 2, e);
                     }
-                    uint32_t em_spd = (uint32_t)sv.mats[sv.light_mat[l]].emission_spd;
-                    lrec[0] = (uint64_t)em_spd | ((uint64_t)lflags << 32);
+                    uint32_t em_spd = (uint32_t)sv.mats[sv.light_mat[l]].emission_spd & 0xFFFFu;
+                    lrec[0] = (uint64_t)em_spd | ((uint64_t)lflags << 16);
                 }
                 /* sampled continuation, :464-472 */
                 V3 in;
                 double dir_pdf;
                 sample_direction(sc, sv, ip, rs, n_draws, in, dir_pdf);
                 EvalCoef e = eval_coefficients(sc, sv, ip, in);
-                vrec[0] = (uint64_t)ip.surface_mat | ((uint64_t)ip.incident_mat << 32);
-                vrec[1] = (uint64_t)ip.transmit_mat | ((uint64_t)e.flags << 32);
-                vrec[2] = (uint64_t)__double_as_longlong(ip.on_dot);
-                vrec[3] = (uint64_t)__double_as_longlong(dir_pdf);
-                store_coef(vrec + 4, e);
+                vrec[0] = mat.bdsf_packed;
+                vrec[1] = (uint64_t)mat.num_bdsfs | ((uint64_t)e.flags << 8) | ((uint64_t)((uint32_t)mat.diffuse_spd & 0xFFFFu) << 16) |
+                          ((uint64_t)((uint32_t)mat.glossy_spd & 0xFFFFu) << 32) | ((uint64_t)((uint32_t)mat.mirror_spd & 0xFFFFu) << 48);
+                vrec[2] = (uint64_t)((uint32_t)sv.mats[ip.incident_mat].refract_spd & 0xFFFFu) |
+                          ((uint64_t)((uint32_t)sv.mats[ip.transmit_mat].refract_spd & 0xFFFFu) << 16) |
+                          ((uint64_t)((uint32_t)sv.mats[ip.transmit_mat].extinct_spd & 0xFFFFu) << 32);
+                vrec[3] = (uint64_t)__double_as_longlong(ip.on_dot);
+                vrec[4] = (uint64_t)__double_as_longlong(dir_pdf);
+                store_coef(vrec + 5, e);
                 shaded += 1;
                 rd = in;
                 ro = ip.position;
@@ -649,8 +662,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void drt_trace_kernel(DevScene sc, Dev
             depth += 1;
             if (terminal || depth >= tp.max_depth)
             {
-                rec[0] = (uint64_t)shaded | ((uint64_t)term << 32);
-                rec[1] = (uint64_t)term_spd;
+                hdr[0] = (uint64_t)shaded | ((uint64_t)term << 16) | ((uint64_t)(term_spd & 0xFFFFu) << 32);
                 alive = false;
             }
         }
@@ -671,66 +683,81 @@ __global__ __launch_bounds__(TRACE_BLOCK) void drt_trace_kernel(DevScene sc, Dev
 
 #define SHADE_BLOCK 256
 #define SHADE_WAVES (SHADE_BLOCK / 64)
+#define SHADE_MAX_SETS 4 /* wavelengths per lane: S <= 64 * SHADE_MAX_SETS */
 
 struct ShadeParams
 {
     uint64_t n_pix;
     uint32_t n_samples, first_sample, vertex_words, path_words;
-    uint32_t n_lights, spds_in_lds;
+    uint32_t n_lights, batch, pad0, pad1;
 };
+
+__device__ __forceinline__ double word_as_double(uint64_t w) { return __longlong_as_double((long long)w); }
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l)
+{
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+/* value of SPD `idx` at wavelength `lam` (REC_NO_SPD = the reference's NULL spectrum, read as 0) */
+template <typename SpdPtr>
+__device__ __forceinline__ double spd_at(SpdPtr spds, uint32_t S, uint32_t idx, uint32_t lam)
+{
+    return idx == REC_NO_SPD ? 0.0 : spds[idx * S + lam];
+}
 
 /* One BDSF sum for one wavelength: bdsf(), src/daily_ray_trace.c:215-229. `bdsf_result` is zeroed
  * once and carried from function to function; functions whose direction test fails leave it (Q1). */
-__device__ __forceinline__ double bdsf_at_wavelength(const DevMaterial &mat, const double *__restrict__ spds, uint32_t S,
-                                                     uint32_t lam, double ir, double tr, double te, double on_dot,
-                                                     double a_in, double spec, double mn_dot, double ct_coef,
-                                                     uint32_t flags, double inv_pi)
+__device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num_bdsfs, double diffuse, double glossy, double mirror,
+                                                     double ir, double tr, double te, double on_dot, double a_in, double spec,
+                                                     double mn_dot, double ct_coef, uint32_t flags, double inv_pi)
 {
     double bdsf_result = 0.0;
     double reflectance = 0.0;
-    for (uint32_t i = 0; i < mat.num_bdsfs; i += 1)
+/* The Fresnel terms are pure f64 arithmetic, so the optimiser would hoist them out of this loop and
+ * run them (divisions, square roots) for every vertex of every material. The empty asm ties each one
+ * to its `case`: only vertices whose material lists the function pay for it. */
+#define DRT_PIN_HERE(x) asm volatile("" : "+v"(x))
+    for (uint32_t i = 0; i < num_bdsfs; i += 1)
     {
-        switch (mat.bdsfs[i])
+        switch ((uint32_t)(list >> (4 * i)) & 15u)
         {
             case DRT_BDSF_bp_diffuse_bdsf: /* src/bdsf.c:105-109 */
-            {
-                double d = mat.diffuse_spd >= 0 ? spds[(size_t)mat.diffuse_spd * S + lam] : 0.0;
-                bdsf_result = (d * inv_pi) * a_in;
+                bdsf_result = (diffuse * inv_pi) * a_in;
                 break;
-            }
             case DRT_BDSF_bp_glossy_bdsf: /* :111-119 */
-            {
-                double g = mat.glossy_spd >= 0 ? spds[(size_t)mat.glossy_spd * S + lam] : 0.0;
-                bdsf_result = (g * spec) * a_in;
+                bdsf_result = (glossy * spec) * a_in;
                 break;
-            }
             case DRT_BDSF_mirror_bdsf: /* :121-132 */
-            {
-                double m = mat.mirror_spd >= 0 ? spds[(size_t)mat.mirror_spd * S + lam] : 0.0;
-                bdsf_result = (flags & FLAG_EQR) ? m : 0.0;
+                bdsf_result = (flags & FLAG_EQR) ? mirror : 0.0;
                 break;
-            }
             case DRT_BDSF_fs_conductor_bdsf: /* :134-146 */
-            {
                 if (flags & FLAG_EQR)
                 {
+                    DRT_PIN_HERE(ir);
                     double c2 = on_dot * on_dot;
                     bdsf_result = conductor_reflectance(ir, tr, te, on_dot, c2, 1.0 - c2);
                 }
                 break;
-            }
             case DRT_BDSF_fs_dielectric_reflectance_bdsf: /* :148-159 */
-            {
-                if (flags & FLAG_EQR) bdsf_result = dielectric_reflectance(ir, tr, on_dot, 1.0 - on_dot * on_dot);
+                if (flags & FLAG_EQR)
+                {
+                    DRT_PIN_HERE(ir);
+                    bdsf_result = dielectric_reflectance(ir, tr, on_dot, 1.0 - on_dot * on_dot);
+                }
                 break;
-            }
             case DRT_BDSF_fs_dielectric_transmittance_bdsf: /* :161-172, :69-76 */
-            {
-                if (flags & FLAG_EQT) bdsf_result = 1.0 - dielectric_reflectance(ir, tr, on_dot, 1.0 - on_dot * on_dot);
+                if (flags & FLAG_EQT)
+                {
+                    DRT_PIN_HERE(ir);
+                    bdsf_result = 1.0 - dielectric_reflectance(ir, tr, on_dot, 1.0 - on_dot * on_dot);
+                }
                 break;
-            }
             case DRT_BDSF_ct_conductor_bdsf: /* :174-186 */
             {
+                DRT_PIN_HERE(ir);
                 double c2 = mn_dot * mn_dot;
                 bdsf_result = conductor_reflectance(ir, tr, te, mn_dot, c2, 1.0 - c2) * ct_coef;
                 break;
@@ -739,117 +766,249 @@ __device__ __forceinline__ double bdsf_at_wavelength(const DevMaterial &mat, con
         }
         reflectance = bdsf_result + reflectance;
     }
+#undef DRT_PIN_HERE
     return reflectance;
 }
 
-__device__ __forceinline__ double word_as_double(uint64_t w) { return __longlong_as_double((long long)w); }
+/*
+ * One pixel per wave, lanes = wavelengths (lane, 64 + lane, ...).
+ *
+ * For each of the pixel's samples in the batch, in order: the path's vertex records arrive by one
+ * coalesced vector load per 64 words (the NEXT sample's load is already in flight while this one is
+ * replayed), every field is lifted into SGPRs with v_readlane, so the record decode and the BDSF
+ * dispatch run on the scalar unit and the vector unit only does the per-wavelength f64 arithmetic:
+ * cast_ray's spectral side (src/daily_ray_trace.c:440-472 with direct_light_contribution :272-332
+ * inlined), the vignette (:615) and render_image's film update (:732-743) on accumulators kept in
+ * registers. The film is read and written once per batch. Waves are persistent (SPD tables staged
+ * into LDS once) and draw chunks of pixels from a global counter, because pixel cost varies.
+ */
+#define SHADE_PREFETCH_REGS 4 /* 64-word registers per path: 256 record words are prefetched, deeper paths fall back */
+#define SHADE_PIXEL_CHUNK 16
 
+template <int NSETS, bool SPDS_IN_LDS>
 __global__ __launch_bounds__(SHADE_BLOCK) void drt_shade_kernel(DevScene sc, ShadeParams sp, const uint64_t *__restrict__ records,
-                                                                 double *__restrict__ film_pixels, double *__restrict__ film_avgs,
-                                                                 double *__restrict__ film_vars)
+                                                                 const uint64_t *__restrict__ headers, double *__restrict__ film_pixels,
+                                                                 double *__restrict__ film_avgs, double *__restrict__ film_vars,
+                                                                 unsigned long long *__restrict__ work_counter)
 {
-    extern __shared__ double lds_spd[];
+    extern __shared__ double lds[];
     const uint32_t S = sc.S;
-    const double *spds = sc.spds;
-    if (sp.spds_in_lds)
+    if (SPDS_IN_LDS)
     {
-        /* SPD block [n_spd][S] is contiguous: coalesced copy into LDS */
-        for (uint32_t k = threadIdx.x; k < sc.n_spd * S; k += SHADE_BLOCK) lds_spd[k] = sc.spds[k];
+        /* the SPD block [n_spd][S] is contiguous: coalesced copy */
+        const uint32_t spd_words = sc.n_spd * S;
+        for (uint32_t k = threadIdx.x; k < spd_words; k += SHADE_BLOCK) lds[k] = sc.spds[k];
         __syncthreads();
-        spds = lds_spd;
     }
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t pix = (uint64_t)blockIdx.x * SHADE_WAVES + wave; /* wave-uniform */
-    if (pix >= sp.n_pix) return;
     const double inv_pi = 1.0 / DRT_PI; /* bp_diffuse: 1.0/PI, src/bdsf.c:107 */
-    const DevMaterial *mats = sc.mats;
+    const uint32_t vw = sp.vertex_words;                 /* power of two >= 16 */
+    const uint32_t vpr = vw <= 64 ? 64u / vw : 0u;       /* vertices per 64-word register (0: records wider than a register) */
+    const uint32_t n_fast = vpr * SHADE_PREFETCH_REGS;   /* vertices covered by the prefetch registers */
 
-    for (uint32_t lam0 = 0; lam0 < S; lam0 += 64)
+    uint32_t lam_c[NSETS];
+#pragma unroll
+    for (int k = 0; k < NSETS; k += 1)
     {
-        const uint32_t lam = lam0 + lane;
-        const bool active = lam < S;
-        const uint32_t lam_c = active ? lam : 0;
+        const uint32_t lam = 64u * k + lane;
+        lam_c[k] = lam < S ? lam : 0;
+    }
+
+    uint64_t chunk_next = 0, chunk_end = 0; /* wave-uniform */
+    for (;;)
+    {
+        if (chunk_next >= chunk_end)
+        {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(work_counter, (unsigned long long)SHADE_PIXEL_CHUNK);
+            base = readlane64(base, 0);
+            if (base >= sp.n_pix) break;
+            chunk_next = base;
+            chunk_end = (base + SHADE_PIXEL_CHUNK < sp.n_pix) ? base + SHADE_PIXEL_CHUNK : sp.n_pix;
+        }
+        const uint64_t pix = chunk_next;
+        chunk_next += 1;
+
         double *px = film_pixels + pix * (uint64_t)(S + 1);
         double *pa = film_avgs + pix * (uint64_t)S;
         double *pv = film_vars + pix * (uint64_t)S;
-        double f_sum = active ? px[lam] : 0.0;
-        double f_avg = active ? pa[lam] : 0.0;
-        double f_var = active ? pv[lam] : 0.0;
-
+        double f_sum[NSETS], f_avg[NSETS], f_var[NSETS];
+#pragma unroll
+        for (int k = 0; k < NSETS; k += 1)
+        {
+            const uint32_t lam = 64u * k + lane;
+            const bool active = lam < S;
+            f_sum[k] = active ? px[lam] : 0.0;
+            f_avg[k] = active ? pa[lam] : 0.0;
+            f_var[k] = active ? pv[lam] : 0.0;
+        }
+        /* headers of all the pixel's samples in one coalesced load: lane s <- sample s */
+        uint64_t h0 = 0, h1 = 0;
+        if (lane < sp.n_samples)
+        {
+            const uint64_t *h = headers + (pix * sp.batch + lane) * REC_HEADER_WORDS;
+            h0 = h[0];
+            h1 = h[1];
+        }
+        const uint64_t *rbase = records + pix * (uint64_t)sp.batch * sp.path_words;
+        uint64_t nxt[SHADE_PREFETCH_REGS];
+        {
+            const uint32_t nw = (uint32_t)(readlane64(h0, 0) & 0xFFFFu) * vw;
+#pragma unroll
+            for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) nxt[k] = (64u * k + lane < nw) ? rbase[64u * k + lane] : 0;
+        }
         for (uint32_t s = 0; s < sp.n_samples; s += 1)
         {
-            const uint64_t *rec = records + ((uint64_t)s * sp.n_pix + pix) * (uint64_t)sp.path_words;
-            const uint64_t h0 = rec[0];
-            const uint32_t n_shaded = (uint32_t)(h0 & 0xffffffffu);
-            const uint32_t term = (uint32_t)(h0 >> 32);
-            double throughput = 1.0; /* const_spectrum(throughput, 1.0), src/daily_ray_trace.c:440 */
-            double dst = 0.0;
+            const uint64_t hs = readlane64(h0, s);
+            const double vignette = word_as_double(readlane64(h1, s));
+            const uint32_t n_shaded = (uint32_t)(hs & 0xFFFFu);
+            const uint32_t term = (uint32_t)(hs >> 16) & 0xFFu;
+            const uint32_t term_spd = (uint32_t)(hs >> 32) & 0xFFFFu;
+            const uint64_t *p_s = rbase + (uint64_t)s * sp.path_words;
+            uint64_t cur[SHADE_PREFETCH_REGS];
+#pragma unroll
+            for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) cur[k] = nxt[k];
+            if (s + 1 < sp.n_samples)
+            {
+                const uint32_t nw = (uint32_t)(readlane64(h0, s + 1) & 0xFFFFu) * vw;
+                const uint64_t *p = p_s + sp.path_words;
+#pragma unroll
+                for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) nxt[k] = (64u * k + lane < nw) ? p[64u * k + lane] : 0;
+            }
+
+            double throughput[NSETS], dst[NSETS];
+#pragma unroll
+            for (int k = 0; k < NSETS; k += 1)
+            {
+                throughput[k] = 1.0; /* const_spectrum(throughput, 1.0), :440 */
+                dst[k] = 0.0;
+            }
             for (uint32_t v = 0; v < n_shaded; v += 1)
             {
-                const uint64_t *vrec = rec + REC_HEADER_WORDS + (uint64_t)v * sp.vertex_words;
-                const uint64_t w0 = vrec[0], w1 = vrec[1];
-                const DevMaterial &mat = mats[(uint32_t)(w0 & 0xffffffffu)];
-                const DevMaterial &imat = mats[(uint32_t)(w0 >> 32)];
-                const DevMaterial &tmat = mats[(uint32_t)(w1 & 0xffffffffu)];
-                const uint32_t sflags = (uint32_t)(w1 >> 32);
-                const double on_dot = word_as_double(vrec[2]);
-                const double dir_pdf = word_as_double(vrec[3]);
-                const double ir = imat.refract_spd >= 0 ? spds[(size_t)imat.refract_spd * S + lam_c] : 0.0;
-                const double tr = tmat.refract_spd >= 0 ? spds[(size_t)tmat.refract_spd * S + lam_c] : 0.0;
-                const double te = tmat.extinct_spd >= 0 ? spds[(size_t)tmat.extinct_spd * S + lam_c] : 0.0;
+                /* the register (and the lane offset in it) that holds this vertex's record */
+                uint64_t src;
+                uint32_t lane0;
+                if (v < n_fast)
+                {
+                    const uint32_t sel = v / vpr;
+                    lane0 = (v - sel * vpr) * vw;
+                    src = sel == 0 ? cur[0] : sel == 1 ? cur[1] : sel == 2 ? cur[2] : cur[3];
+                }
+                else
+                {
+                    /* deep path or a record wider than a register: fetch the first 64 words of the vertex now */
+                    lane0 = 0;
+                    src = (lane < vw) ? p_s[(uint64_t)v * vw + lane] : 0;
+                }
+                const uint64_t list = readlane64(src, lane0 + 0);
+                const uint64_t w1 = readlane64(src, lane0 + 1);
+                const uint64_t w2 = readlane64(src, lane0 + 2);
+                const double on_dot = word_as_double(readlane64(src, lane0 + 3));
+                const double dir_pdf = word_as_double(readlane64(src, lane0 + 4));
+                const uint32_t num_bdsfs = (uint32_t)(w1 & 0xFFu);
+                const uint32_t sflags = (uint32_t)(w1 >> 8) & 0xFFu;
+                const uint32_t i_diffuse = (uint32_t)(w1 >> 16) & 0xFFFFu, i_glossy = (uint32_t)(w1 >> 32) & 0xFFFFu;
+                const uint32_t i_mirror = (uint32_t)(w1 >> 48) & 0xFFFFu;
+                const uint32_t i_ir = (uint32_t)(w2)&0xFFFFu, i_tr = (uint32_t)(w2 >> 16) & 0xFFFFu, i_te = (uint32_t)(w2 >> 32) & 0xFFFFu;
 
+                double diffuse[NSETS], glossy[NSETS], mirror[NSETS], ir[NSETS], tr[NSETS], te[NSETS], contribution[NSETS];
+#pragma unroll
+                for (int k = 0; k < NSETS; k += 1)
+                {
+                    if (SPDS_IN_LDS)
+                    {
+                        const double *t = lds;
+                        diffuse[k] = spd_at(t, S, i_diffuse, lam_c[k]); glossy[k] = spd_at(t, S, i_glossy, lam_c[k]);
+                        mirror[k] = spd_at(t, S, i_mirror, lam_c[k]);   ir[k] = spd_at(t, S, i_ir, lam_c[k]);
+                        tr[k] = spd_at(t, S, i_tr, lam_c[k]);           te[k] = spd_at(t, S, i_te, lam_c[k]);
+                    }
+                    else
+                    {
+                        const double *t = sc.spds;
+                        diffuse[k] = spd_at(t, S, i_diffuse, lam_c[k]); glossy[k] = spd_at(t, S, i_glossy, lam_c[k]);
+                        mirror[k] = spd_at(t, S, i_mirror, lam_c[k]);   ir[k] = spd_at(t, S, i_ir, lam_c[k]);
+                        tr[k] = spd_at(t, S, i_tr, lam_c[k]);           te[k] = spd_at(t, S, i_te, lam_c[k]);
+                    }
+                    contribution[k] = 0.0;
+                }
                 /* direct_light_contribution, :272-332 */
-                double contribution = 0.0;
                 for (uint32_t l = 0; l < sp.n_lights; l += 1)
                 {
-                    const uint64_t *lrec = vrec + REC_VERTEX_WORDS + (uint64_t)l * REC_LIGHT_WORDS;
-                    const uint64_t lw0 = lrec[0];
-                    const uint32_t lflags = (uint32_t)(lw0 >> 32);
+                    const uint32_t off = REC_VERTEX_WORDS + l * REC_LIGHT_WORDS;
+                    uint64_t lw[REC_LIGHT_WORDS];
+                    if (off + REC_LIGHT_WORDS <= 64 || v < n_fast)
+                    {
+#pragma unroll
+                        for (int k = 0; k < REC_LIGHT_WORDS; k += 1) lw[k] = readlane64(src, lane0 + off + k);
+                    }
+                    else
+                    {
+                        /* light block beyond the register: uniform loads straight from the record */
+                        const uint64_t *lp = p_s + (uint64_t)v * vw + off;
+#pragma unroll
+                        for (int k = 0; k < REC_LIGHT_WORDS; k += 1) lw[k] = readlane64(lp[k], 0);
+                    }
+                    const uint32_t lflags = (uint32_t)(lw[0] >> 16) & 0xFFu;
                     if (!(lflags & FLAG_VISIBLE)) continue;
-                    const int32_t em_spd = (int32_t)(uint32_t)(lw0 & 0xffffffffu);
-                    const double c = word_as_double(lrec[1]);
-                    double reflectance = bdsf_at_wavelength(mat, spds, S, lam_c, ir, tr, te, on_dot, word_as_double(lrec[2]),
-                                                            word_as_double(lrec[3]), word_as_double(lrec[4]),
-                                                            word_as_double(lrec[5]), lflags, inv_pi);
-                    const double em = em_spd >= 0 ? spds[(size_t)em_spd * S + lam_c] : 0.0;
-                    contribution = contribution + reflectance; /* :323 */
-                    contribution = contribution * em;          /* :324 */
-                    contribution = contribution * c;           /* :326-327 */
+                    const uint32_t i_em = (uint32_t)(lw[0] & 0xFFFFu);
+                    const double c = word_as_double(lw[1]);
+#pragma unroll
+                    for (int k = 0; k < NSETS; k += 1)
+                    {
+                        double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse[k], glossy[k], mirror[k], ir[k], tr[k], te[k], on_dot,
+                                                                word_as_double(lw[2]), word_as_double(lw[3]), word_as_double(lw[4]),
+                                                                word_as_double(lw[5]), lflags, inv_pi);
+                        const double em = SPDS_IN_LDS ? spd_at((const double *)lds, S, i_em, lam_c[k]) : spd_at(sc.spds, S, i_em, lam_c[k]);
+                        contribution[k] = contribution[k] + reflectance; /* :323 */
+                        contribution[k] = contribution[k] * em;          /* :324 */
+                        contribution[k] = contribution[k] * c;           /* :326-327 */
+                    }
                 }
-                dst = dst + throughput * contribution; /* :461-462 */
-                double reflectance = bdsf_at_wavelength(mat, spds, S, lam_c, ir, tr, te, on_dot, word_as_double(vrec[4]),
-                                                        word_as_double(vrec[5]), word_as_double(vrec[6]),
-                                                        word_as_double(vrec[7]), sflags, inv_pi);
-                reflectance = reflectance * dir_pdf;   /* :468 */
-                throughput = throughput * reflectance; /* :469 */
+                const double s_a_in = word_as_double(readlane64(src, lane0 + 5)), s_spec = word_as_double(readlane64(src, lane0 + 6));
+                const double s_mn = word_as_double(readlane64(src, lane0 + 7)), s_ct = word_as_double(readlane64(src, lane0 + 8));
+#pragma unroll
+                for (int k = 0; k < NSETS; k += 1)
+                {
+                    dst[k] = dst[k] + throughput[k] * contribution[k]; /* :461-462 */
+                    double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse[k], glossy[k], mirror[k], ir[k], tr[k], te[k], on_dot,
+                                                            s_a_in, s_spec, s_mn, s_ct, sflags, inv_pi);
+                    reflectance = reflectance * dir_pdf;            /* :468 */
+                    throughput[k] = throughput[k] * reflectance;    /* :469 */
+                }
             }
-            if (term == 1) /* emissive black body hit, :452-457 */
+            const double denom = (double)(sp.first_sample + s + 1);
+#pragma unroll
+            for (int k = 0; k < NSETS; k += 1)
             {
-                const int32_t em_spd = (int32_t)(uint32_t)(rec[1] & 0xffffffffu);
-                const double em = em_spd >= 0 ? spds[(size_t)em_spd * S + lam_c] : 0.0;
-                dst = dst + throughput * em;
+                if (term == 1) /* emissive black body hit, :452-457 */
+                {
+                    const double em = SPDS_IN_LDS ? spd_at((const double *)lds, S, term_spd, lam_c[k]) : spd_at(sc.spds, S, term_spd, lam_c[k]);
+                    dst[k] = dst[k] + throughput[k] * em;
+                }
+                const double contribution = dst[k] * vignette; /* :615 */
+                /* film update, src/daily_ray_trace.c:732-743 */
+                f_sum[k] = f_sum[k] + contribution;
+                double t0 = contribution - f_avg[k];
+                double t1 = t0;
+                t0 = t0 / denom;
+                f_avg[k] = f_avg[k] + t0;
+                t0 = contribution - f_avg[k];
+                t0 = t1 * t0;
+                f_var[k] = f_var[k] + t0;
             }
-            const double vignette = word_as_double(rec[2]);
-            const double contribution = dst * vignette; /* :615 */
-
-            /* film update, src/daily_ray_trace.c:732-743 */
-            f_sum = f_sum + contribution;
-            double t0 = contribution - f_avg;
-            double t1 = t0;
-            t0 = t0 / (double)(sp.first_sample + s + 1);
-            f_avg = f_avg + t0;
-            t0 = contribution - f_avg;
-            t0 = t1 * t0;
-            f_var = f_var + t0;
         }
-        if (active)
+#pragma unroll
+        for (int k = 0; k < NSETS; k += 1)
         {
-            px[lam] = f_sum;
-            pa[lam] = f_avg;
-            pv[lam] = f_var;
+            const uint32_t lam = 64u * k + lane;
+            if (lam < S)
+            {
+                px[lam] = f_sum[k];
+                pa[lam] = f_avg[k];
+                pv[lam] = f_var[k];
+            }
         }
-        if (lam0 == 0 && lane == 0) px[S] += (double)sp.n_samples * 1.0; /* filter sum: += 1.0 per sample, :733 */
+        if (lane == 0) px[S] += (double)sp.n_samples * 1.0; /* filter sum: += 1.0 per sample, :733 */
     }
 }
 

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -47,7 +48,7 @@ struct drt_context
     std::vector<void *> allocations; /* scene tables */
     double *d_pixels = nullptr, *d_avgs = nullptr, *d_vars = nullptr;
     bool    own_film = false;
-    uint64_t *d_records = nullptr;
+    uint64_t *d_records = nullptr, *d_headers = nullptr;
     uint32_t  batch_spp = 1;
     uint32_t  vertex_words = 0, path_words = 0;
     int32_t  *d_hits = nullptr;
@@ -58,7 +59,7 @@ struct drt_context
 
     bool   scene_in_lds = true, spds_in_lds = true;
     size_t trace_lds = 0, shade_lds = 0;
-    int    trace_grid_cap = 0;
+    int    trace_grid_cap = 0, shade_grid_cap = 0;
     uint64_t n_pix = 0;
 
     std::vector<hipEvent_t> ev; /* triples: trace start, trace end / shade start, shade end */
@@ -201,6 +202,7 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene)
             uint32_t b = m.bdsfs[j];
             if (b >= DRT_NUM_BDSFS) return fail(-2, "material %u: unknown bdsf id %u", i, b);
             dm.bdsfs[j] = b;
+            dm.bdsf_packed |= (uint64_t)b << (4 * j);
             if (b == DRT_BDSF_bp_glossy_bdsf) dm.needs |= NEED_GLOSSY;
             if (b == DRT_BDSF_mirror_bdsf || b == DRT_BDSF_fs_conductor_bdsf || b == DRT_BDSF_fs_dielectric_reflectance_bdsf) dm.needs |= NEED_EQR;
             if (b == DRT_BDSF_fs_dielectric_transmittance_bdsf) dm.needs |= NEED_EQT;
@@ -230,9 +232,40 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene)
     ctx->trace_lds = trace_lds_bytes(n_surf, n_lights, scene->num_materials);
     ctx->scene_in_lds = ctx->trace_lds <= 64 * 1024;
     if (!ctx->scene_in_lds) ctx->trace_lds = 0;
-    ctx->shade_lds = (size_t)scene->num_spds * S * 8;
-    ctx->spds_in_lds = ctx->shade_lds <= 64 * 1024;
-    if (!ctx->spds_in_lds) ctx->shade_lds = 0;
+    ctx->spds_in_lds = (size_t)scene->num_spds * S * 8 <= 64 * 1024;
+    return 0;
+}
+
+template <int NSETS>
+static int launch_shade_sets(drt_context *ctx, uint32_t grid, const ShadeParams &sp)
+{
+    if (ctx->spds_in_lds)
+        hipLaunchKernelGGL((drt_shade_kernel<NSETS, true>), dim3(grid), dim3(SHADE_BLOCK), ctx->shade_lds, ctx->stream, ctx->dsc, sp,
+                           ctx->d_records, ctx->d_headers, ctx->d_pixels, ctx->d_avgs, ctx->d_vars, ctx->d_counters + DRT_NUM_COUNTERS + 1);
+    else
+        hipLaunchKernelGGL((drt_shade_kernel<NSETS, false>), dim3(grid), dim3(SHADE_BLOCK), ctx->shade_lds, ctx->stream, ctx->dsc, sp,
+                           ctx->d_records, ctx->d_headers, ctx->d_pixels, ctx->d_avgs, ctx->d_vars, ctx->d_counters + DRT_NUM_COUNTERS + 1);
+    return 0;
+}
+
+static int launch_shade(drt_context *ctx, uint32_t grid, const ShadeParams &sp)
+{
+    switch ((ctx->dsc.S + 63) / 64)
+    {
+        case 1: return launch_shade_sets<1>(ctx, grid, sp);
+        case 2: return launch_shade_sets<2>(ctx, grid, sp);
+        case 3: return launch_shade_sets<3>(ctx, grid, sp);
+        default: return launch_shade_sets<4>(ctx, grid, sp);
+    }
+}
+
+template <int NSETS>
+static int shade_occupancy(drt_context *ctx, int *per_cu)
+{
+    if (ctx->spds_in_lds)
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, drt_shade_kernel<NSETS, true>, SHADE_BLOCK, ctx->shade_lds));
+    else
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, drt_shade_kernel<NSETS, false>, SHADE_BLOCK, ctx->shade_lds));
     return 0;
 }
 
@@ -267,8 +300,13 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
 
     const uint32_t S = scene->num_wavelengths;
     ctx->n_pix = (uint64_t)params->tile_w * params->tile_h;
-    ctx->vertex_words = REC_VERTEX_WORDS + REC_LIGHT_WORDS * ctx->dsc.n_lights;
-    ctx->path_words = REC_HEADER_WORDS + ctx->vertex_words * params->max_depth;
+    /* vertex record stride: fixed part + one block per light, rounded up to a power of two (>= 16 words) so a
+     * vertex never straddles the shade kernel's 64-word prefetch registers */
+    ctx->vertex_words = 16;
+    while (ctx->vertex_words < REC_VERTEX_WORDS + REC_LIGHT_WORDS * ctx->dsc.n_lights) ctx->vertex_words *= 2;
+    ctx->path_words = ctx->vertex_words * params->max_depth;
+    if (scene->num_spds >= REC_NO_SPD) return fail(-2, "too many SPDs for the 16-bit record indices");
+    if (S > 64 * SHADE_MAX_SETS) return fail(-2, "more than %d wavelengths", 64 * SHADE_MAX_SETS);
 
     /* batch: enough paths in flight to fill the chip many times over, bounded record memory */
     uint32_t batch = params->batch_spp;
@@ -277,6 +315,7 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
         uint64_t target_paths = 4ull << 20;
         batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, target_paths / std::max<uint64_t>(ctx->n_pix, 1)));
     }
+    batch = std::min<uint32_t>(batch, 64); /* one header lane per sample in the shade kernel */
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     size_t film_bytes = (size_t)ctx->n_pix * (3 * (size_t)S + 1) * 8;
@@ -285,6 +324,7 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     size_t rec_bytes = (size_t)ctx->n_pix * batch * ctx->path_words * 8;
     if (rec_bytes + film_bytes > free_b) return fail(-3, "not enough device memory: need %zu bytes", rec_bytes + film_bytes);
     HIP_TRY(hipMalloc((void **)&ctx->d_records, rec_bytes));
+    HIP_TRY(hipMalloc((void **)&ctx->d_headers, (size_t)ctx->n_pix * batch * REC_HEADER_WORDS * 8));
 
     HIP_TRY(hipMalloc((void **)&ctx->d_pixels, (size_t)ctx->n_pix * (S + 1) * 8));
     HIP_TRY(hipMalloc((void **)&ctx->d_avgs, (size_t)ctx->n_pix * S * 8));
@@ -293,8 +333,8 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     HIP_TRY(hipMemsetAsync(ctx->d_pixels, 0, (size_t)ctx->n_pix * (S + 1) * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_avgs, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_vars, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
-    HIP_TRY(hipMalloc((void **)&ctx->d_counters, (DRT_NUM_COUNTERS + 1) * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 1) * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMalloc((void **)&ctx->d_counters, (DRT_NUM_COUNTERS + 2) * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 2) * sizeof(unsigned long long), ctx->stream));
 
     /* persistent trace grid: as many workgroups as the chip keeps resident */
     hipDeviceProp_t prop;
@@ -305,7 +345,25 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     else
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, drt_trace_kernel<false>, TRACE_BLOCK, 0));
     if (per_cu < 1) per_cu = 1;
+    if (const char *e = getenv("DRT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e)); /* tuning knob */
     ctx->trace_grid_cap = prop.multiProcessorCount * per_cu;
+    /* shade kernel LDS: SPD tables + two record buffers per wave */
+    ctx->shade_lds = ctx->spds_in_lds ? (size_t)scene->num_spds * S * 8 : 0;
+    int s_per_cu = 0;
+    switch ((S + 63) / 64)
+    {
+        case 1: rc = shade_occupancy<1>(ctx, &s_per_cu); break;
+        case 2: rc = shade_occupancy<2>(ctx, &s_per_cu); break;
+        case 3: rc = shade_occupancy<3>(ctx, &s_per_cu); break;
+        default: rc = shade_occupancy<4>(ctx, &s_per_cu); break;
+    }
+    if (rc) return rc;
+    if (s_per_cu < 1) s_per_cu = 1;
+    if (const char *e = getenv("DRT_SHADE_BLOCKS_PER_CU")) s_per_cu = std::max(1, atoi(e)); /* tuning knob */
+    ctx->shade_grid_cap = prop.multiProcessorCount * s_per_cu;
+    if (getenv("DRT_VERBOSE"))
+        fprintf(stderr, "drt: %d CUs, trace %d blocks/CU (lds %zu), shade %d blocks/CU (lds %zu), batch %u, path_words %u\n",
+                prop.multiProcessorCount, per_cu, ctx->trace_lds, s_per_cu, ctx->shade_lds, ctx->batch_spp, ctx->path_words);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -338,6 +396,7 @@ extern "C" void drt_destroy(drt_context *ctx)
         (void)hipFree(ctx->d_vars);
     }
     (void)hipFree(ctx->d_records);
+    (void)hipFree(ctx->d_headers);
     (void)hipFree(ctx->d_hits);
     (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_xyz);
@@ -443,21 +502,22 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
         tp.vertex_words = ctx->vertex_words;
         tp.path_words = ctx->path_words;
         tp.hits_sample_offset = done;
+        tp.batch = ctx->batch_spp;
 
         hipEvent_t ev[3];
         int rc = next_events(ctx, ev);
         if (rc) return rc;
         unsigned long long *work = ctx->d_counters + DRT_NUM_COUNTERS;
-        HIP_TRY(hipMemsetAsync(work, 0, sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(hipMemsetAsync(work, 0, 2 * sizeof(unsigned long long), ctx->stream)); /* trace + shade work queues */
         uint64_t blocks_needed = (tp.n_paths + TRACE_BLOCK - 1) / TRACE_BLOCK;
         uint32_t grid = (uint32_t)std::min<uint64_t>(blocks_needed, (uint64_t)ctx->trace_grid_cap);
         HIP_TRY(hipEventRecord(ev[0], ctx->stream));
         if (ctx->scene_in_lds)
             hipLaunchKernelGGL(drt_trace_kernel<true>, dim3(grid), dim3(TRACE_BLOCK), ctx->trace_lds, ctx->stream, ctx->dsc,
-                               ctx->dcam, tp, ctx->d_records, ctx->d_hits, ctx->d_counters, work);
+                               ctx->dcam, tp, ctx->d_records, ctx->d_headers, ctx->d_hits, ctx->d_counters, work);
         else
             hipLaunchKernelGGL(drt_trace_kernel<false>, dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->dsc, ctx->dcam, tp,
-                               ctx->d_records, ctx->d_hits, ctx->d_counters, work);
+                               ctx->d_records, ctx->d_headers, ctx->d_hits, ctx->d_counters, work);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[1], ctx->stream));
 
@@ -468,10 +528,10 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
         sp.vertex_words = ctx->vertex_words;
         sp.path_words = ctx->path_words;
         sp.n_lights = ctx->dsc.n_lights;
-        sp.spds_in_lds = ctx->spds_in_lds ? 1u : 0u;
-        uint32_t sgrid = (uint32_t)((ctx->n_pix + SHADE_WAVES - 1) / SHADE_WAVES);
-        hipLaunchKernelGGL(drt_shade_kernel, dim3(sgrid), dim3(SHADE_BLOCK), ctx->shade_lds, ctx->stream, ctx->dsc, sp,
-                           ctx->d_records, ctx->d_pixels, ctx->d_avgs, ctx->d_vars);
+        sp.batch = ctx->batch_spp;
+        uint32_t sgrid = (uint32_t)std::min<uint64_t>((ctx->n_pix + SHADE_WAVES - 1) / SHADE_WAVES, (uint64_t)ctx->shade_grid_cap);
+        rc = launch_shade(ctx, sgrid, sp);
+        if (rc) return rc;
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[2], ctx->stream));
     }
@@ -496,7 +556,7 @@ extern "C" int drt_reset_film(drt_context *ctx)
     HIP_TRY(hipMemsetAsync(ctx->d_pixels, 0, (size_t)ctx->n_pix * (S + 1) * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_avgs, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_vars, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 1) * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 2) * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->trace_ms = ctx->shade_ms = 0.0;
     return 0;

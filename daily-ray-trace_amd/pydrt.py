@@ -256,7 +256,7 @@ _hip = None
 def hip_lib():
     global _hip
     if _hip is None:
-        path = os.path.join(HERE, "libdrt_hip.so")
+        path = os.environ.get("DRT_HIP_LIB") or os.path.join(HERE, "libdrt_hip.so")  # DRT_HIP_LIB: A/B builds when profiling
         if not os.path.exists(path):
             raise RuntimeError("libdrt_hip.so is not built (no fallback exists): run __graft_entry__.build()")
         L = C.CDLL(path)

@@ -1,0 +1,16 @@
+"""Fixed workload for rocprofv3: cornell_plane_light 1024^2, depth 8, SPP samples in batches of BATCH."""
+import os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "daily-ray-trace_amd"))
+import pydrt
+spp = int(os.environ.get("SPP", "16")); batch = int(os.environ.get("BATCH", "8")); size = int(os.environ.get("SIZE", "1024"))
+depth = int(os.environ.get("DEPTH", "8"))
+bundle = pydrt.load_scene(os.path.join(REPO, "scenes", "cornell_plane_light.scn"), size, size)
+params = pydrt.make_params(size, size, spp=spp, max_depth=depth, seed=1, batch_spp=batch)
+r = pydrt.Renderer(bundle, params)
+r.render(0, batch); r.synchronize(); r.reset_film()
+t0 = time.time(); r.render(0, spp); r.synchronize(); t1 = time.time()
+st = r.stats()
+print("workload %dx%d spp %d batch %d depth %d: wall %.2f ms, %.1f Mpaths/s, trace %.2f ms, shade %.2f ms" % (
+    size, size, spp, batch, depth, (t1 - t0) * 1e3, size * size * spp / (t1 - t0) / 1e6, st.trace_ms, st.shade_ms))
+r.close()
