@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X render path.
+
+Metric (BASELINE.json): Mpaths/s (pixels*spp/s), Cornell 1024^2, depth 8 -- cornell_plane_light.scn at
+1024x1024, 256 spp, max depth 8 (BASELINE configs[1]); plus the HBM-roofline fraction of the dominant kernel.
+
+A "step" is one full render of that frame: every sample of every pixel through the trace and the shade+film
+kernels, with scene, SPD tables and film resident in HBM when the clock starts. With N > 1 GPUs the frame is
+tiled row-cyclically over the ranks (one process per GPU) and each step ends with the single gather of the
+three film buffers to rank 0 over RCCL; total work is fixed, so scaling is "strong".
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel with the algorithmic byte model of
+SURVEY 8d (see DESIGN.md "Measurement"); `cpu_baseline` is the reference's own CPU path (oracle/_ref, when that
+library travelled with the repo) or the CPU oracle port, timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "daily-ray-trace_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def algorithmic_bytes(S, v_int, v_shade):
+    """SURVEY 8d byte model per path, split by kernel.
+    B_film = 2*8*(S+1) + 2*8*S + 2*8*S           sum(+filter), mean, variance read-modify-write
+    B_state = 2*(48 + 8*S + 4 + 8 + 4)            ray, throughput spectrum, pixel id, rng, depth: per closest-hit iteration
+    B_rad = 2*8*S                                 radiance spectrum RMW per shaded vertex
+    The spectral part (film, radiance, throughput spectrum) is the shade kernel's; the ray/rng/id state is the
+    trace kernel's."""
+    b_film = 2 * 8 * (S + 1) + 2 * 8 * S + 2 * 8 * S
+    b_state = 2 * (48 + 8 * S + 4 + 8 + 4)
+    b_rad = 2 * 8 * S
+    shade = b_film + v_shade * b_rad + v_int * (2 * 8 * S)
+    trace = v_int * (b_state - 2 * 8 * S)
+    return {"path": b_film + v_int * b_state + v_shade * b_rad, "shade": shade, "trace": trace}
+
+
+def cpu_baseline(bundle_loader, width, height, depth, seconds_target=12.0):
+    """Times the CPU path on a bounded sample of the same workload: whole rows of the 1024^2 frame, 1 thread.
+    Mpaths/s does not depend on spp, so the sample is 1 spp over as many rows as fit the time budget."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle_py as O
+    import pydrt
+    bundle = bundle_loader()
+    use_ref = O.ref_available()
+    # calibrate on 8 rows in the middle of the frame, then size the sample
+    def run(rows, threads=1):
+        p = pydrt.make_params(width, height, spp=1, max_depth=depth, seed=1, y0=(height - rows) // 2, tile_h=rows)
+        t0 = time.perf_counter()
+        if use_ref and threads == 1:
+            O.ref_render_tile(bundle, p)
+        else:
+            O.oracle_render_tile(bundle, p, math_mode=O.MATH_REFERENCE, num_threads=threads)
+        return rows * width / (time.perf_counter() - t0)
+    rate = run(8)
+    rows = int(max(8, min(height, rate * seconds_target / width)))
+    rate = run(rows)
+    out = {"value": round(rate / 1e6, 4), "unit": "Mpaths/s", "cores": 1, "kind": "reference" if use_ref else "port",
+           "sample": "%d centre rows x %d px, 1 spp, depth %d of the same frame (%d paths), single thread%s" % (
+               rows, width, depth, rows * width, ", compiled reference path (oracle/_ref)" if use_ref else ", CPU oracle port")}
+    ncpu = os.cpu_count() or 1
+    if ncpu > 1:
+        rows_mt = int(min(height, rows * min(ncpu, 16)))
+        t_rate = run(rows_mt, threads=ncpu)
+        out["all_cores"] = {"value": round(t_rate / 1e6, 4), "cores": ncpu, "kind": "port",
+                            "sample": "%d rows, %d threads (row-parallel CPU oracle)" % (rows_mt, ncpu)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=0, help="samples per kernel pair (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import pydrt
+    import drt_dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d processes" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    W = H = args.size
+    scene_file = os.path.join(REPO, "scenes", "cornell_plane_light.scn")
+    bundle = pydrt.load_scene(scene_file, W, H)
+    S = bundle.S
+    y0, tile_h, stride = drt_dist.rank_rows(H, rank, world)
+    params = pydrt.make_params(W, H, spp=args.spp, max_depth=args.depth, seed=1, y0=y0, tile_h=tile_h, row_stride=stride,
+                               device=local_rank, batch_spp=args.batch)
+    dev = torch.device("cuda", local_rank)
+    n_tile = tile_h * W
+    film = [torch.zeros((n_tile, S + 1), dtype=torch.float64, device=dev), torch.zeros((n_tile, S), dtype=torch.float64, device=dev),
+            torch.zeros((n_tile, S), dtype=torch.float64, device=dev)]
+    r = pydrt.Renderer(bundle, params)
+    r.bind_film(film[0].data_ptr(), film[1].data_ptr(), film[2].data_ptr())
+    stream = torch.cuda.current_stream()
+    r.set_stream(stream.cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gather_ms = [0.0]
+
+    def step():
+        for t in film:
+            t.zero_()
+        r.render(0, args.spp)
+        if world > 1:
+            t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+            t0.record()
+            for t, c in zip(film, (S + 1, S, S)):
+                drt_dist.gather_tiles(t.reshape(tile_h, W, c), H, W, rank, world)
+            t1.record()
+            torch.cuda.synchronize()
+            gather_ms[0] += t0.elapsed_time(t1)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    r.synchronize()
+    st0 = r.stats()
+    gather_ms[0] = 0.0
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    r.synchronize()
+    st1 = r.stats()
+    batch_spp = r.batch_spp()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel time from HIP events recorded by the library on the launch stream (timed region only)
+    paths_rank = st1.paths - st0.paths
+    trace_ms = st1.trace_ms - st0.trace_ms
+    shade_ms = st1.shade_ms - st0.shade_ms
+    v_int = (st1.closest_hit_scans - st0.closest_hit_scans) / max(paths_rank, 1)
+    v_shade = (st1.shaded_vertices - st0.shaded_vertices) / max(paths_rank, 1)
+
+    if rank == 0:
+        total_paths = W * H * args.spp * args.steps
+        value = total_paths / elapsed / 1e6
+        model = algorithmic_bytes(S, v_int, v_shade)
+        dominant = "shade" if shade_ms >= trace_ms else "trace"
+        dom_ms = max(shade_ms, trace_ms)
+        # per launch: paths per kernel launch and its average duration (launches = batches)
+        paths_per_launch = batch_spp * n_tile
+        launches = max(1, round(paths_rank / max(paths_per_launch, 1)))
+        avg_launch_ms = dom_ms / launches
+        achieved = model[dominant] * paths_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == "cornell_plane_light %dx%d depth %d" % (W, H, args.depth):
+                    traffic = round(tj["hbm_bytes_per_path"][dominant] * paths_per_launch)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpaths/s (pixels*spp/s) Cornell 1024^2 depth 8; achieved HBM GB/s % of peak",
+            "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cornell_plane_light.scn %dx%d, %d spp, depth %d (BASELINE configs[1])" % (W, H, args.spp, args.depth),
+                       "film": "full spectral (sum+filter, mean, variance x %d wavelengths)" % S,
+                       "partition": "rows cyclic over %d rank(s), one gather of the film per step" % world,
+                       "paths_per_step": W * H * args.spp},
+            "roofline": {"bound": "hbm", "kernel": "drt_%s_kernel" % dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "launch": {"paths": paths_per_launch, "avg_ms": round(avg_launch_ms, 4), "count": launches,
+                                                        "algorithmic_bytes": round(model[dominant] * paths_per_launch)},
+                         "algorithmic_bytes_per_path": {k: round(v, 1) for k, v in model.items()},
+                         "kernel_ms_per_step": {"trace": round(trace_ms / args.steps, 3), "shade": round(shade_ms / args.steps, 3)},
+                         "whole_path_GBs": round(model["path"] * (total_paths / elapsed) / 1e9, 1),
+                         "v_int": round(v_int, 4), "v_shade": round(v_shade, 4),
+                         "note": "achieved = SURVEY 8d algorithmic bytes of the dominant kernel / its HIP-event time on rank 0; "
+                                 "traffic = HBM bytes per launch of that kernel from the committed rocprofv3 PMC profile (profiles/traffic.json), when it matches"},
+        }
+        if world > 1:
+            out["gather_ms_per_step"] = round(gather_ms[0] / args.steps, 3)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(lambda: pydrt.load_scene(scene_file, W, H), W, H, args.depth)
+        print(json.dumps(out))
+    r.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -127,7 +127,7 @@ __device__ __forceinline__ double drt_rng(uint64_t &state, uint32_t &draws)
     return (double)(uint32_t)(x >> 33) / 2147483647.0;
 }
 
-/* ---- sincos: same specification as drt_oracle_sincos (oracle/drt_oracle.c) ------------------- */
+/* ---- sincos: the specification the oracle's sincos restates (see DESIGN.md "Arithmetic contract") ---- */
 __device__ __forceinline__ void drt_sincos(double t, double &s, double &c)
 {
     const double TWO_OVER_PI = 6.36619772367581382433e-01;

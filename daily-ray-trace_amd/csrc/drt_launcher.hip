@@ -312,7 +312,7 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     uint32_t batch = params->batch_spp;
     if (batch == 0)
     {
-        uint64_t target_paths = 4ull << 20;
+        uint64_t target_paths = 16ull << 20;
         batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, target_paths / std::max<uint64_t>(ctx->n_pix, 1)));
     }
     batch = std::min<uint32_t>(batch, 64); /* one header lane per sample in the shade kernel */
@@ -377,6 +377,7 @@ extern "C" drt_context *drt_create(const drt_scene *scene, const drt_camera *cam
     {
         std::string keep = g_last_error;
         drt_destroy(ctx);
+        (void)hipGetLastError();
         g_last_error = keep;
         return nullptr;
     }
@@ -464,6 +465,7 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
 {
     if (!ctx) return fail(-1, "null context");
     HIP_TRY(hipSetDevice(ctx->device));
+    (void)hipGetLastError(); /* drop a stale error of an earlier, unrelated call: launches below are checked against a clean slate */
     const drt_params &p = ctx->params;
     if (p.flags & DRT_FLAG_RECORD_HITS)
     {
@@ -627,6 +629,8 @@ extern "C" int drt_get_stats(drt_context *ctx, drt_stats *out)
     out->total_ms = ctx->trace_ms + ctx->shade_ms;
     return 0;
 }
+
+extern "C" uint32_t drt_batch_spp(drt_context *ctx) { return ctx ? ctx->batch_spp : 0; }
 
 extern "C" int drt_render_tile(const drt_scene *scene, const drt_camera *camera, const drt_params *params,
                                double *dst_pixels, double *dst_avgs, double *dst_vars, drt_stats *stats)

@@ -20,41 +20,6 @@ static f64 now_ms(void)
     return (f64)ts.tv_sec * 1000.0 + (f64)ts.tv_nsec * 1e-6;
 }
 
-/* 40-byte header + row-major pixels, y = 0 first (src/daily_ray_trace.c:667-680, :758-770) */
-int drt_host_write_spd(const char *path, u32 width, u32 height, u32 num_wl, u32 has_filter, f64 min_wl, f64 interval,
-                       const f64 *pixels)
-{
-    FILE *f = fopen(path, "wb");
-    if (!f) return -1;
-    spd_file_header header;
-    memset(&header, 0, sizeof(header));
-    header.id = 0xedfeefbe;
-    header.width_in_pixels = width;
-    header.height_in_pixels = height;
-    header.number_of_wavelengths = num_wl;
-    header.has_filter_values = has_filter;
-    header.min_wavelength = min_wl;
-    header.wavelength_interval = interval;
-    size_t per_pixel = (size_t)num_wl + (has_filter ? 1 : 0);
-    size_t count = (size_t)width * height * per_pixel;
-    int ok = fwrite(&header, sizeof(header), 1, f) == 1 && fwrite(pixels, sizeof(f64), count, f) == count;
-    fclose(f);
-    return ok ? 0 : -1;
-}
-
-int drt_host_read_spd(const char *path, spd_file_header *header, f64 **pixels)
-{
-    FILE *f = fopen(path, "rb");
-    if (!f) return -1;
-    if (fread(header, sizeof(*header), 1, f) != 1 || header->id != 0xedfeefbe) { fclose(f); return -2; }
-    size_t per_pixel = (size_t)header->number_of_wavelengths + (header->has_filter_values ? 1 : 0);
-    size_t count = (size_t)header->width_in_pixels * header->height_in_pixels * per_pixel;
-    *pixels = (f64 *)malloc(count * sizeof(f64));
-    if (fread(*pixels, sizeof(f64), count, f) != count) { fclose(f); free(*pixels); *pixels = NULL; return -3; }
-    fclose(f);
-    return 0;
-}
-
 int render_image_ex(config_arguments *config, const drt_host_options *opt, drt_stats *stats_out)
 {
     u32 width = config->output_width, height = config->output_height;

@@ -51,8 +51,9 @@ static const char *next_char(const char *c, char want)
  *  - a sample is counted for every newline that still has a digit somewhere after it;
  *  - a number starts at the first DIGIT found, so a leading '-' or '.' is not part of it;
  *  - if the first wavelength is < 10 the file is taken to be in micrometres (x1000);
- *  - the table is walked forward only; past its end the next entry reads as (0, 0)
- *    (zero-initialised arrays in the reference), which the lerp then extrapolates towards.
+ *  - the table is walked forward only. A grid wavelength below the file's first entry extrapolates
+ *    the first segment (as in the reference). One above the file's last entry makes the reference
+ *    walk off its 128-entry arrays (undefined behaviour); here it extrapolates the last segment.
  */
 u32 drt_host_csv_to_spectrum(const char *csv_path, f64 min_wl, f64 wl_interval, u32 num_samples, f64 *dst)
 {
@@ -96,7 +97,7 @@ u32 drt_host_csv_to_spectrum(const char *csv_path, f64 min_wl, f64 wl_interval, 
     for (u32 s = 0; s < num_samples; s += 1)
     {
         f64 sample_wl = min_wl + ((f64)s) * wl_interval;
-        for (; k + 1 <= count && wl[k + 1] < sample_wl; k += 1);
+        for (; k + 2 < count && wl[k + 1] < sample_wl; k += 1);
         dst[s] = lerp(sample_wl, wl[k], wl[k + 1], val[k], val[k + 1]);
     }
     free(wl);

@@ -275,6 +275,8 @@ def hip_lib():
         L.drt_read_xyz.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.drt_read_hit_indices.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_uint64]
         L.drt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.drt_batch_spp.restype = C.c_uint32
+        L.drt_batch_spp.argtypes = [C.c_void_p]
         L.drt_render_tile.argtypes = [C.POINTER(Scene), C.POINTER(Camera), C.POINTER(Params), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(Stats)]
         L.drt_selftest_arith.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -285,7 +287,7 @@ def hip_lib():
 
 HIP_SYMBOLS = ["drt_last_error", "drt_device_count", "drt_create", "drt_destroy", "drt_bind_film", "drt_set_stream",
                "drt_render", "drt_synchronize", "drt_reset_film", "drt_film_device_ptrs", "drt_read_film",
-               "drt_read_xyz", "drt_read_hit_indices", "drt_get_stats", "drt_render_tile", "drt_selftest_arith"]
+               "drt_read_xyz", "drt_read_hit_indices", "drt_get_stats", "drt_batch_spp", "drt_render_tile", "drt_selftest_arith"]
 
 
 def _check(rc, what):
@@ -357,6 +359,9 @@ class Renderer:
         _check(self.L.drt_read_hit_indices(self.ctx, _ptr(out, C.c_int32), n), "drt_read_hit_indices")
         return out
 
+    def batch_spp(self):
+        return int(self.L.drt_batch_spp(self.ctx))
+
     def stats(self):
         st = Stats()
         _check(self.L.drt_get_stats(self.ctx, C.byref(st)), "drt_get_stats")
@@ -386,3 +391,44 @@ def selftest_arith(op, a, b=None, device=0):
     _check(hip_lib().drt_selftest_arith(device, op, _ptr(a, C.c_double), _ptr(b, C.c_double), _ptr(out, C.c_double), n),
            "drt_selftest_arith")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Synthetic scenes
+
+def _xorshift64_stream(seed):
+    x = seed & 0xFFFFFFFFFFFFFFFF
+    while True:
+        x ^= (x << 13) & 0xFFFFFFFFFFFFFFFF
+        x ^= x >> 7
+        x ^= (x << 17) & 0xFFFFFFFFFFFFFFFF
+        yield (x >> 33) / 2147483647.0
+
+
+def synthetic_sphere_scene(n_spheres, width, height, seed=0x5EED, spectra_dir=None):
+    """The many-sphere scene of BASELINE config 5: n spheres, centres uniform in [-20,20]x[-20,20]x[-40,0], radii
+    uniform [0.05,0.35] from xorshift64 (draw order cx,cy,cz,r), materials round-robin over {blue, green, red, white,
+    teal plastic, mirror, rough gold}, one 10x10 plane light at y=25 (emission constant 1), vacuum base + escape;
+    pinhole camera (0,0,30) -> (0,0,-20), fov 60. Materials/SPDs come from cornell_plane_light.scn via the host loader."""
+    base = load_scene(os.path.join(REPO, "scenes", "cornell_plane_light.scn"), width, height, spectra_dir=spectra_dir)
+    names = base.material_names()
+    mats = []
+    for i in range(int(base.scene.num_materials)):
+        m = base.scene.materials[i]
+        mats.append({k: getattr(m, k) for k in ("is_black_body", "is_emissive", "shininess", "roughness", "emission_spd",
+                                                 "diffuse_spd", "glossy_spd", "mirror_spd", "refract_spd", "extinct_spd",
+                                                 "dir_func")} | {"bdsfs": [m.bdsfs[j] for j in range(m.num_bdsfs)]})
+    cycle = [names.index(n) for n in ("blue_plastic", "green_plastic", "red_plastic", "white_plastic", "teal_plastic",
+                                      "mirror", "gold")]
+    g = _xorshift64_stream(seed)
+    surfaces = []
+    for i in range(n_spheres):
+        cx = -20.0 + 40.0 * next(g)
+        cy = -20.0 + 40.0 * next(g)
+        cz = -40.0 + 40.0 * next(g)
+        r = 0.05 + 0.30 * next(g)
+        surfaces.append({"type": GEO_SPHERE, "material": cycle[i % len(cycle)], "position": (cx, cy, cz), "radius": r})
+    u, v, n = plane_from_points((-5.0, 25.0, 5.0), (5.0, 25.0, 5.0), (-5.0, 25.0, -5.0))
+    surfaces.append({"type": GEO_PLANE, "material": names.index("light"), "position": (-5.0, 25.0, 5.0), "u": u, "v": v, "normal": n})
+    cam = init_camera((0.0, 0.0, 30.0), (0.0, 0.0, -20.0), 0.0, 60.0, 6.0, 0.3, 0.0, width, height)
+    return build_scene(surfaces, mats, base.spds(), int(base.scene.base_material), int(base.scene.escape_material), cam)

@@ -213,6 +213,8 @@ int drt_read_xyz(drt_context *ctx, double *xyz);
  * (sample - first_sample_of_last_call, tile row, tile column). */
 int drt_read_hit_indices(drt_context *ctx, int32_t *dst, uint64_t capacity_paths);
 int drt_get_stats(drt_context *ctx, drt_stats *out);
+/* Samples per pixel one trace+shade kernel pair processes (the launch granularity); 0 on error. */
+uint32_t drt_batch_spp(drt_context *ctx);
 
 /*
  * One-shot form matching the reference's loop: host buffers, caller-owned,

@@ -1,0 +1,51 @@
+"""Shared test cases: the scenes/configs every parity test and the golden generator iterate over."""
+import os
+
+import numpy as np
+
+import pydrt
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def scene_path(name):
+    return os.path.join(REPO, "scenes", name)
+
+
+# name -> (scene file or generator tag, width, height, spp, depth, seed, pixel scheme)
+RENDER_CASES = {
+    "plane_light_16": ("cornell_plane_light.scn", 16, 16, 4, 8, 1, pydrt.FILM_SAMPLE_RANDOM),
+    "plane_light_48": ("cornell_plane_light.scn", 48, 48, 4, 8, 1, pydrt.FILM_SAMPLE_RANDOM),
+    "plane_light_d1": ("cornell_plane_light.scn", 32, 24, 3, 1, 7, pydrt.FILM_SAMPLE_RANDOM),
+    "plane_light_d2": ("cornell_plane_light.scn", 32, 24, 3, 2, 7, pydrt.FILM_SAMPLE_RANDOM),
+    "plane_light_d16": ("cornell_plane_light.scn", 24, 24, 2, 16, 3, pydrt.FILM_SAMPLE_RANDOM),
+    "plane_light_center": ("cornell_plane_light.scn", 24, 24, 2, 4, 1, pydrt.FILM_SAMPLE_CENTER),
+    "init_cornell": ("init_cornell.scn", 32, 32, 4, 4, 1, pydrt.FILM_SAMPLE_RANDOM),  # config 1 scene (legacy syntax)
+    "large_box": ("cornell_large_box.scn", 32, 32, 3, 16, 1, pydrt.FILM_SAMPLE_RANDOM),  # config 3 scene
+    "gold_mirror": ("cornell_gold_mirror.scn", 32, 32, 4, 8, 1, pydrt.FILM_SAMPLE_RANDOM),  # config 4 scene
+    "downward": ("cornell_downward.scn", 24, 24, 2, 4, 1, pydrt.FILM_SAMPLE_RANDOM),  # legacy, roll 180
+    "lights": ("test_lights.scn", 32, 32, 4, 6, 5, pydrt.FILM_SAMPLE_RANDOM),  # plane + sphere + point light
+    "lens": ("test_lens.scn", 24, 24, 3, 4, 2, pydrt.FILM_SAMPLE_RANDOM),  # thin-lens camera
+    "spheres_1500": ("@spheres:1500", 32, 32, 2, 6, 9, pydrt.FILM_SAMPLE_RANDOM),  # config 5 generator, reduced
+}
+
+
+def load_case(name):
+    scene, w, h, spp, depth, seed, scheme = RENDER_CASES[name]
+    if scene.startswith("@spheres:"):
+        bundle = pydrt.synthetic_sphere_scene(int(scene.split(":")[1]), w, h)
+    else:
+        bundle = pydrt.load_scene(scene_path(scene), w, h)
+    params = pydrt.make_params(w, h, spp=spp, max_depth=depth, seed=seed, pixel_scheme=scheme)
+    return bundle, params
+
+
+def rel_err(a, b):
+    """max |a-b| / max|b| -- the scale-relative error used for film buffers."""
+    scale = float(np.max(np.abs(b)))
+    return float(np.max(np.abs(a - b))) / (scale if scale > 0 else 1.0)
+
+
+def xyz_rel_err(a, b, floor=1e-9):
+    """per-pixel, per-channel relative error of XYZ (the metric BASELINE.json names), with an absolute floor."""
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))

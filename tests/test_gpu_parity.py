@@ -1,0 +1,220 @@
+"""GPU (-m gpu): the HIP path, through the C-ABI, against the CPU oracle on the same seeded inputs.
+
+Bars: closest-hit surface indices, path statistics and RNG draw counts bit-exact; film buffers within 1e-12
+(scale-relative; the only arithmetic that differs is pow(): ocml vs glibc, <= 1 ulp); per-pixel XYZ within 1e-9
+relative of the oracle and of the golden vectors from the compiled reference (BASELINE.json asks for <= 1e-4)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_py as O
+import pydrt
+
+pytestmark = pytest.mark.gpu
+
+FILM_TOL = 1e-12
+XYZ_TOL = 1e-9
+
+
+def hip_render(bundle, params, record_hits=True, batch=None):
+    p = pydrt.make_params(int(params.width), int(params.height), spp=int(params.spp), max_depth=int(params.max_depth),
+                          seed=int(params.seed), x0=int(params.x0), y0=int(params.y0), tile_w=int(params.tile_w),
+                          tile_h=int(params.tile_h), row_stride=int(params.row_stride), first_sample=int(params.first_sample),
+                          pixel_scheme=int(params.pixel_scheme), batch_spp=int(params.batch_spp) if batch is None else batch,
+                          flags=pydrt.FLAG_RECORD_HITS if record_hits else 0)
+    r = pydrt.Renderer(bundle, p)
+    r.render()
+    px, av, va = r.read_film()
+    hits = r.read_hit_indices(int(p.spp)) if record_hits else None
+    xyz = r.read_xyz()
+    st = r.stats()
+    r.close()
+    return px, av, va, hits, xyz, st
+
+
+def test_device_arithmetic_is_ieee_and_matches_the_oracle_spec():
+    assert pydrt.hip_lib().drt_device_count() >= 1
+    rng = np.random.default_rng(0)
+    a = np.concatenate([rng.uniform(0, 100, 100000), 10.0 ** rng.uniform(-300, 300, 100000), [0.0, 1e-320, 4.0]])
+    b = np.concatenate([rng.uniform(-3, 3, 100000), 10.0 ** rng.uniform(-150, 150, 100000), [1.0, 3.0, 2.0]])
+    assert np.array_equal(pydrt.selftest_arith(0, a), np.sqrt(a)), "f64 sqrt is not correctly rounded"
+    with np.errstate(over="ignore", under="ignore"):
+        assert np.array_equal(pydrt.selftest_arith(1, a, b), a / b), "f64 divide is not correctly rounded"
+    t = np.concatenate([rng.uniform(-1.0, 7.0, 20000), [0.0, np.pi / 4, np.pi / 2, np.pi, 2 * np.pi, 3 * np.pi / 4]])
+    sc = pydrt.selftest_arith(2, t).reshape(-1, 2)
+    L = O.oracle_lib()
+    s_, c_ = C.c_double(), C.c_double()
+    for i in range(t.size):
+        L.drt_oracle_sincos(float(t[i]), C.byref(s_), C.byref(c_))
+        assert sc[i, 0] == s_.value and sc[i, 1] == c_.value
+    assert np.abs(sc[:, 0] - np.sin(t)).max() <= 2.3e-16 and np.abs(sc[:, 1] - np.cos(t)).max() <= 2.3e-16
+    x = rng.uniform(0, 1, 100000)
+    for y in (100.0, 32.0, 16.0, 2.5):
+        got, ref = pydrt.selftest_arith(3, x, np.full_like(x, y)), np.power(x, y)
+        m = ref > 1e-290
+        assert np.max(np.abs(got[m] - ref[m]) / ref[m]) <= 4.5e-16  # pow: within 2 ulp of glibc
+    keys = rng.integers(0, 2 ** 62, 5000, dtype=np.uint64)
+    got = pydrt.selftest_arith(4, keys.view(np.float64))
+    for i in range(0, 5000, 7):
+        L.drt_oracle_seed_path(int(keys[i]))
+        v = [L.drt_oracle_rng() for _ in range(4)][-1]
+        assert got[i] == v
+
+
+@pytest.mark.parametrize("name", list(cases.RENDER_CASES))
+def test_hip_matches_oracle_and_golden(name, golden_dir):
+    bundle, params = cases.load_case(name)
+    px, av, va, hits, xyz, st = hip_render(bundle, params)
+    opx, oav, ova, ohits, ost = O.oracle_render_tile(bundle, params, want_hits=True, math_mode=O.MATH_DEVICE)
+    assert np.array_equal(hits, ohits), "%d closest-hit indices differ" % int((hits != ohits).sum())
+    assert (st.paths, st.closest_hit_scans, st.shaded_vertices, st.shadow_scans, st.rng_draws) == \
+           (ost.paths, ost.closest_hit_scans, ost.shaded_vertices, ost.shadow_scans, ost.rng_draws)
+    S = bundle.S
+    assert np.array_equal(px[:, S], opx[:, S])
+    assert cases.rel_err(px, opx) <= FILM_TOL and cases.rel_err(av, oav) <= FILM_TOL and cases.rel_err(va, ova) <= FILM_TOL
+    assert cases.xyz_rel_err(xyz, O.oracle_film_to_xyz(bundle, opx)) <= XYZ_TOL
+    g = np.load(os.path.join(golden_dir, "render_%s.npz" % name), allow_pickle=False)
+    assert cases.xyz_rel_err(xyz, g["xyz"]) <= XYZ_TOL  # against the compiled reference (north star: 1e-4)
+    if "hits" in g.files:
+        assert np.array_equal(hits, g["hits"])  # bit-exact hit-primitive indices against the reference
+    for got, key in ((px[:, :S].sum(axis=1), "pix_sum"), (av.sum(axis=1), "avg_sum"), (va.sum(axis=1), "var_sum")):
+        assert cases.rel_err(got, g[key]) <= 1e-11
+
+
+def test_batching_resume_and_tiles_do_not_change_a_bit():
+    bundle, params = cases.load_case("plane_light_48")
+    base = hip_render(bundle, params, batch=4)
+    for batch in (1, 3):
+        other = hip_render(bundle, params, batch=batch)
+        for a, b in zip(base[:5], other[:5]):
+            assert np.array_equal(a, b)
+    # resume: samples [0,2) then [2,4) on the same film == [0,4)
+    p = pydrt.make_params(48, 48, spp=4, max_depth=8, seed=1, batch_spp=2)
+    r = pydrt.Renderer(bundle, p)
+    r.render(0, 2)
+    r.render(2, 2)
+    px, av, va = r.read_film()
+    r.close()
+    assert np.array_equal(px, base[0]) and np.array_equal(av, base[1]) and np.array_equal(va, base[2])
+    # row-cyclic tiles (the multi-GPU partition) reassemble to the full frame
+    S = bundle.S
+    full = base[0].reshape(48, 48, S + 1)
+    for rank in range(3):
+        pt = pydrt.make_params(48, 48, spp=4, max_depth=8, seed=1, y0=rank, tile_h=16, row_stride=3)
+        tpx = hip_render(bundle, pt, record_hits=False)[0]
+        assert np.array_equal(tpx.reshape(16, 48, S + 1), full[rank::3])
+    # a sub-rectangle
+    pt = pydrt.make_params(48, 48, spp=4, max_depth=8, seed=1, x0=8, y0=4, tile_w=24, tile_h=10)
+    tpx = hip_render(bundle, pt, record_hits=False)[0]
+    assert np.array_equal(tpx.reshape(10, 24, S + 1), full[4:14, 8:32])
+
+
+def test_one_shot_render_tile_accumulates_into_host_buffers():
+    bundle, params = cases.load_case("plane_light_16")
+    px, av, va, st = pydrt.render_tile(bundle, params)
+    opx, oav, ova, _, _ = O.oracle_render_tile(bundle, params, math_mode=O.MATH_DEVICE)
+    assert cases.rel_err(px, opx) <= FILM_TOL and cases.rel_err(av, oav) <= FILM_TOL
+    assert st.paths == 16 * 16 * 4 and st.total_ms > 0
+    # second call with first_sample = 4 continues the same buffers
+    L = pydrt.hip_lib()
+    p2 = pydrt.make_params(16, 16, spp=4, max_depth=8, seed=1, first_sample=4)
+    st2 = pydrt.Stats()
+    f64p = C.POINTER(C.c_double)
+    rc = L.drt_render_tile(C.byref(bundle.scene), C.byref(bundle.camera), C.byref(p2), px.ctypes.data_as(f64p), av.ctypes.data_as(f64p),
+                           va.ctypes.data_as(f64p), C.byref(st2))
+    assert rc == 0
+    p8 = pydrt.make_params(16, 16, spp=8, max_depth=8, seed=1)
+    o8 = O.oracle_render_tile(bundle, p8, math_mode=O.MATH_DEVICE)
+    assert cases.rel_err(px, o8[0]) <= FILM_TOL and cases.rel_err(av, o8[1]) <= FILM_TOL and cases.rel_err(va, o8[2]) <= FILM_TOL
+    assert np.all(px[:, bundle.S] == 8.0)
+
+
+def test_errors_are_reported_not_swallowed():
+    bundle, params = cases.load_case("plane_light_16")
+    L = pydrt.hip_lib()
+    bad = pydrt.make_params(16, 16, spp=1, max_depth=0)
+    assert not L.drt_create(C.byref(bundle.scene), C.byref(bundle.camera), C.byref(bad))
+    assert b"depth" in L.drt_last_error()
+    bad_dev = pydrt.make_params(16, 16, spp=1, max_depth=2, device=99)
+    assert not L.drt_create(C.byref(bundle.scene), C.byref(bundle.camera), C.byref(bad_dev))
+    assert len(L.drt_last_error()) > 0
+    r = pydrt.Renderer(bundle, params)  # hit recording off
+    r.render()
+    with pytest.raises(RuntimeError):
+        r.read_hit_indices(4)
+    r.close()
+
+
+def test_large_scene_outside_lds():
+    """BASELINE config 5's generator (10k spheres: SoA tables read from HBM, not LDS), reduced image size."""
+    bundle = pydrt.synthetic_sphere_scene(10000, 48, 48)
+    params = pydrt.make_params(48, 48, spp=2, max_depth=8, seed=11)
+    px, av, va, hits, xyz, st = hip_render(bundle, params)
+    opx, oav, ova, ohits, ost = O.oracle_render_tile(bundle, params, want_hits=True, math_mode=O.MATH_DEVICE, num_threads=8)
+    assert np.array_equal(hits, ohits) and (hits >= 0).any()
+    assert (st.closest_hit_scans, st.shaded_vertices, st.rng_draws) == (ost.closest_hit_scans, ost.shaded_vertices, ost.rng_draws)
+    assert cases.rel_err(px, opx) <= FILM_TOL and cases.rel_err(va, ova) <= FILM_TOL
+
+
+def test_full_size_properties_config2():
+    """BASELINE config 2 geometry (cornell_plane_light 1024x1024, depth 8) at 8 spp: size-independent properties,
+    plus two image rows checked bit-for-bit against the oracle."""
+    w = h = 1024
+    spp = 8
+    bundle = pydrt.load_scene(cases.scene_path("cornell_plane_light.scn"), w, h)
+    p = pydrt.make_params(w, h, spp=spp, max_depth=8, seed=1)
+    r = pydrt.Renderer(bundle, p)
+    r.render(0, spp)
+    px, av, va = r.read_film()
+    st = r.stats()
+    S = bundle.S
+    assert st.paths == w * h * spp
+    assert np.all(px[:, S] == float(spp))                      # filter sums count the samples exactly
+    assert np.isfinite(px).all() and np.isfinite(av).all() and np.isfinite(va).all()
+    assert (va >= -1e-18).all()                                   # running variance sums are sums of (c-m_old)(c-m_new) >= 0
+    np.testing.assert_allclose(av, px[:, :S] / spp, rtol=1e-9, atol=1e-13)  # running mean == sum / n
+    assert 2.45 < st.closest_hit_scans / st.paths < 2.65         # SURVEY: 2.551 scans, 1.645 shaded vertices per path
+    assert 1.55 < st.shaded_vertices / st.paths < 1.75
+    # idempotence: same samples into a zeroed film give the same bits
+    r.reset_film()
+    r.render(0, spp)
+    px2, av2, va2 = r.read_film()
+    assert np.array_equal(px, px2) and np.array_equal(av, av2) and np.array_equal(va, va2)
+    # split across calls == one call
+    r.reset_film()
+    r.render(0, 3)
+    r.render(3, spp - 3)
+    px3, _, va3 = r.read_film()
+    assert np.array_equal(px, px3) and np.array_equal(va, va3)
+    r.close()
+    # two rows of the full image against the oracle
+    for y in (300, 777):
+        pt = pydrt.make_params(w, h, spp=spp, max_depth=8, seed=1, y0=y, tile_h=1)
+        opx, oav, ova, _, _ = O.oracle_render_tile(bundle, pt, math_mode=O.MATH_DEVICE)
+        full = px.reshape(h, w, S + 1)[y]
+        assert cases.rel_err(full, opx) <= FILM_TOL
+        assert cases.rel_err(va.reshape(h, w, S)[y], ova) <= FILM_TOL
+
+
+def test_torch_owned_film_and_stream():
+    """PyTorch as plumbing: film tensors allocated by torch, kernels on torch's current stream."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    bundle, params = cases.load_case("plane_light_48")
+    S, n = bundle.S, 48 * 48
+    dev = torch.device("cuda:0")
+    t_px = torch.zeros((n, S + 1), dtype=torch.float64, device=dev)
+    t_av = torch.zeros((n, S), dtype=torch.float64, device=dev)
+    t_va = torch.zeros((n, S), dtype=torch.float64, device=dev)
+    r = pydrt.Renderer(bundle, params)
+    r.bind_film(t_px.data_ptr(), t_av.data_ptr(), t_va.data_ptr())
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    r.render()
+    torch.cuda.synchronize()
+    opx, oav, ova, _, _ = O.oracle_render_tile(bundle, params, math_mode=O.MATH_DEVICE)
+    assert cases.rel_err(t_px.cpu().numpy(), opx) <= FILM_TOL and cases.rel_err(t_va.cpu().numpy(), ova) <= FILM_TOL
+    r.close()

@@ -1,0 +1,56 @@
+"""CPU, only where oracle/_ref was built (this container): the oracle against the REAL reference code,
+bit for bit, at sizes the golden files do not hold (incl. BASELINE config 1 in full: 256x256, 4 spp, depth 4)."""
+import numpy as np
+import pytest
+
+import cases
+import oracle_py as O
+import pydrt
+
+pytestmark = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
+
+
+@pytest.mark.parametrize("name", list(cases.RENDER_CASES))
+def test_film_bit_identical(name):
+    bundle, params = cases.load_case(name)
+    rp, ra, rv = O.ref_render_tile(bundle, params)
+    op, oa, ov, _, _ = O.oracle_render_tile(bundle, params, math_mode=O.MATH_REFERENCE)
+    assert np.array_equal(rp, op) and np.array_equal(ra, oa) and np.array_equal(rv, ov, equal_nan=True)
+
+
+def test_config1_full_size_bit_identical():
+    """BASELINE.json configs[0]: init_cornell.scn 256x256, 4 spp, depth 4, single thread, fixed seed."""
+    bundle = pydrt.load_scene(cases.scene_path("init_cornell.scn"), 256, 256)
+    params = pydrt.make_params(256, 256, spp=4, max_depth=4, seed=1)
+    rp, ra, rv = O.ref_render_tile(bundle, params)
+    op, oa, ov, _, st = O.oracle_render_tile(bundle, params, math_mode=O.MATH_REFERENCE)
+    assert st.paths == 256 * 256 * 4
+    assert np.array_equal(rp, op) and np.array_equal(ra, oa) and np.array_equal(rv, ov)
+
+
+def test_hit_sequences_and_replay_identity():
+    """The hit-index log comes from replaying cast_ray with the reference's own functions; the replay must give
+    the bits of the reference's real cast_ray, and the oracle must log the same surfaces."""
+    bundle, params = cases.load_case("plane_light_16")
+    hits, replay, real = O.ref_trace_hits(bundle, params)
+    assert np.array_equal(replay, real)
+    _, _, _, ohits, _ = O.oracle_render_tile(bundle, params, want_hits=True, math_mode=O.MATH_REFERENCE)
+    assert np.array_equal(hits, ohits)
+    assert (hits[:, 0] >= -1).all() and (hits == -1).any() and (hits >= 0).any()
+
+
+def test_traversal_order_independence_of_the_reference():
+    """with per-path seeding the reference's own sample_scene gives the same spectrum whether the
+    pixels are visited forward or in reverse."""
+    import ctypes as C
+    bundle, params = cases.load_case("plane_light_16")
+    R = O.ref_lib()
+    R.ref_set_scene(C.byref(bundle.scene))
+    S = bundle.S
+    filt = C.c_double()
+    fwd = np.zeros((16 * 16, S)); rev = np.zeros((16 * 16, S))
+    order = [(x, y) for y in range(16) for x in range(16)]
+    for buf, seq in ((fwd, order), (rev, order[::-1])):
+        for (x, y) in seq:
+            R.ref_sample_scene(C.byref(bundle.camera), C.byref(params), x, y, 2, buf[y * 16 + x].ctypes.data_as(C.POINTER(C.c_double)), C.byref(filt))
+    assert np.array_equal(fwd, rev)
