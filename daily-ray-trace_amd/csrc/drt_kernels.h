@@ -62,6 +62,8 @@ struct DevMaterial
     double   refract_i0, refract_i1; /* refract_spd at the two samples around trans_wl (value_at_wl) */
     uint32_t bdsfs[DRT_MAX_BDSFS];
     uint64_t bdsf_packed; /* bdsfs[] as 4-bit fields */
+    uint32_t vertex_flags; /* FLAG_PLASTIC when the list is exactly {bp_diffuse_bdsf, bp_glossy_bdsf} */
+    uint32_t pad1;
 };
 
 struct DevScene
@@ -102,16 +104,19 @@ struct DevCamera
 /*     w5..w8 = |n.in|, glossy pow term, |n.m|, GGX coefficient (sampled direction), w9 unused      */
 /*  per light (6 words):                                                                           */
 /*     w0 = emission SPD (0-15) | flags (16-23), w1 = atten * area, w2..w5 = the four coefficients  */
-/*  flags: bit0 in == mirror direction, bit1 in == refracted direction, bit2 light visible         */
-/*  SPD index 0xFFFF = no spectrum (reads as zeros).                                               */
+/*  flags: bit0 in == mirror direction, bit1 in == refracted direction, bit2 light visible,        */
+/*         bit3 (vertex) plain two-lobe plastic: shade kernel takes its straight-line path          */
+/*  SPD indices are rows of the DEVICE table: the scene's rows, then one derived row diffuse*(1/pi) */
+/*  per diffuse SPD (w1's "diffuse" field points at it), then one all-zero row that stands for a   */
+/*  missing spectrum (NULL in the reference).                                                       */
 
 #define REC_HEADER_WORDS 2
 #define REC_VERTEX_WORDS 10
 #define REC_LIGHT_WORDS 6
-#define REC_NO_SPD 0xFFFFu
 #define FLAG_EQR 1u
 #define FLAG_EQT 2u
 #define FLAG_VISIBLE 4u
+#define FLAG_PLASTIC 8u /* vertex flags only: the BDSF list is exactly {bp_diffuse_bdsf, bp_glossy_bdsf} */
 
 struct TraceParams
 {
@@ -416,11 +421,14 @@ __device__ __forceinline__ void camera_ray(const DevCamera &cam, uint32_t scheme
 /* The trace kernel                                                                                */
 
 #define TRACE_BLOCK 256
+#ifndef DRT_TRACE_WAVES_PER_SIMD
+#define DRT_TRACE_WAVES_PER_SIMD 3 /* register budget: launch_bounds' 2nd argument is waves per SIMD */
+#endif
 
 /* LDS carve-up (8-byte aligned): surfaces, lights, then u32 tables, then materials (see trace_lds_bytes in the launcher) */
 
 template <bool SCENE_IN_LDS>
-__global__ __launch_bounds__(TRACE_BLOCK) void drt_trace_kernel(DevScene sc, DevCamera cam, TraceParams tp,
+__global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_trace_kernel(DevScene sc, DevCamera cam, TraceParams tp,
                                                                  uint64_t *__restrict__ records, uint64_t *__restrict__ headers,
                                                                  int32_t *__restrict__ hits, unsigned long long *__restrict__ counters,
                                                                  unsigned long long *__restrict__ work_counter)
@@ -647,7 +655,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void drt_trace_kernel(DevScene sc, Dev
                 sample_direction(sc, sv, ip, rs, n_draws, in, dir_pdf);
                 EvalCoef e = eval_coefficients(sc, sv, ip, in);
                 vrec[0] = mat.bdsf_packed;
-                vrec[1] = (uint64_t)mat.num_bdsfs | ((uint64_t)e.flags << 8) | ((uint64_t)((uint32_t)mat.diffuse_spd & 0xFFFFu) << 16) |
+                vrec[1] = (uint64_t)mat.num_bdsfs | ((uint64_t)(e.flags | mat.vertex_flags) << 8) | ((uint64_t)((uint32_t)mat.diffuse_spd & 0xFFFFu) << 16) |
                           ((uint64_t)((uint32_t)mat.glossy_spd & 0xFFFFu) << 32) | ((uint64_t)((uint32_t)mat.mirror_spd & 0xFFFFu) << 48);
                 vrec[2] = (uint64_t)((uint32_t)sv.mats[ip.incident_mat].refract_spd & 0xFFFFu) |
                           ((uint64_t)((uint32_t)sv.mats[ip.transmit_mat].refract_spd & 0xFFFFu) << 16) |
@@ -682,6 +690,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void drt_trace_kernel(DevScene sc, Dev
 /* The shade + film kernel                                                                         */
 
 #define SHADE_BLOCK 256
+#ifndef DRT_SHADE_WAVES_PER_SIMD
+#define DRT_SHADE_WAVES_PER_SIMD 4
+#endif
 #define SHADE_WAVES (SHADE_BLOCK / 64)
 #define SHADE_MAX_SETS 4 /* wavelengths per lane: S <= 64 * SHADE_MAX_SETS */
 
@@ -701,18 +712,18 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l)
     return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
-/* value of SPD `idx` at wavelength `lam` (REC_NO_SPD = the reference's NULL spectrum, read as 0) */
+/* value of SPD row `idx` at wavelength `lam` */
 template <typename SpdPtr>
 __device__ __forceinline__ double spd_at(SpdPtr spds, uint32_t S, uint32_t idx, uint32_t lam)
 {
-    return idx == REC_NO_SPD ? 0.0 : spds[idx * S + lam];
+    return spds[idx * S + lam]; /* a missing spectrum is the table's all-zero row */
 }
 
 /* One BDSF sum for one wavelength: bdsf(), src/daily_ray_trace.c:215-229. `bdsf_result` is zeroed
  * once and carried from function to function; functions whose direction test fails leave it (Q1). */
-__device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num_bdsfs, double diffuse, double glossy, double mirror,
+__device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num_bdsfs, double diffuse_pi, double glossy, double mirror,
                                                      double ir, double tr, double te, double on_dot, double a_in, double spec,
-                                                     double mn_dot, double ct_coef, uint32_t flags, double inv_pi)
+                                                     double mn_dot, double ct_coef, uint32_t flags)
 {
     double bdsf_result = 0.0;
     double reflectance = 0.0;
@@ -724,8 +735,8 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
     {
         switch ((uint32_t)(list >> (4 * i)) & 15u)
         {
-            case DRT_BDSF_bp_diffuse_bdsf: /* src/bdsf.c:105-109 */
-                bdsf_result = (diffuse * inv_pi) * a_in;
+            case DRT_BDSF_bp_diffuse_bdsf: /* src/bdsf.c:105-109; diffuse_pi = diffuse_spd * (1/PI), a per-material table */
+                bdsf_result = diffuse_pi * a_in;
                 break;
             case DRT_BDSF_bp_glossy_bdsf: /* :111-119 */
                 bdsf_result = (glossy * spec) * a_in;
@@ -786,7 +797,7 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
 #define SHADE_PIXEL_CHUNK 16
 
 template <int NSETS, bool SPDS_IN_LDS>
-__global__ __launch_bounds__(SHADE_BLOCK) void drt_shade_kernel(DevScene sc, ShadeParams sp, const uint64_t *__restrict__ records,
+__global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_shade_kernel(DevScene sc, ShadeParams sp, const uint64_t *__restrict__ records,
                                                                  const uint64_t *__restrict__ headers, double *__restrict__ film_pixels,
                                                                  double *__restrict__ film_avgs, double *__restrict__ film_vars,
                                                                  unsigned long long *__restrict__ work_counter)
@@ -801,7 +812,6 @@ __global__ __launch_bounds__(SHADE_BLOCK) void drt_shade_kernel(DevScene sc, Sha
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
-    const double inv_pi = 1.0 / DRT_PI; /* bp_diffuse: 1.0/PI, src/bdsf.c:107 */
     const uint32_t vw = sp.vertex_words;                 /* power of two >= 16 */
     const uint32_t vpr = vw <= 64 ? 64u / vw : 0u;       /* vertices per 64-word register (0: records wider than a register) */
     const uint32_t n_fast = vpr * SHADE_PREFETCH_REGS;   /* vertices covered by the prefetch registers */
@@ -911,28 +921,73 @@ __global__ __launch_bounds__(SHADE_BLOCK) void drt_shade_kernel(DevScene sc, Sha
                 const uint32_t i_mirror = (uint32_t)(w1 >> 48) & 0xFFFFu;
                 const uint32_t i_ir = (uint32_t)(w2)&0xFFFFu, i_tr = (uint32_t)(w2 >> 16) & 0xFFFFu, i_te = (uint32_t)(w2 >> 32) & 0xFFFFu;
 
-                double diffuse[NSETS], glossy[NSETS], mirror[NSETS], ir[NSETS], tr[NSETS], te[NSETS], contribution[NSETS];
+                const double *table = SPDS_IN_LDS ? (const double *)lds : sc.spds;
+                const double s_a_in = word_as_double(readlane64(src, lane0 + 5)), s_spec = word_as_double(readlane64(src, lane0 + 6));
+                double contribution[NSETS];
+#pragma unroll
+                for (int k = 0; k < NSETS; k += 1) contribution[k] = 0.0;
+
+                if (sflags & FLAG_PLASTIC)
+                {
+                    /* the common material, straight-line: bdsf() over {bp_diffuse_bdsf, bp_glossy_bdsf}
+                     * = (glossy*spec)*a + ((diffuse/pi)*a + 0), src/bdsf.c:105-119 through src/daily_ray_trace.c:215-229 */
+                    double diffuse_pi[NSETS], glossy[NSETS];
+#pragma unroll
+                    for (int k = 0; k < NSETS; k += 1)
+                    {
+                        diffuse_pi[k] = spd_at(table, S, i_diffuse, lam_c[k]);
+                        glossy[k] = spd_at(table, S, i_glossy, lam_c[k]);
+                    }
+                    for (uint32_t l = 0; l < sp.n_lights; l += 1) /* direct_light_contribution, :272-332 */
+                    {
+                        const uint32_t off = REC_VERTEX_WORDS + l * REC_LIGHT_WORDS;
+                        uint64_t lw[4];
+                        if (off + REC_LIGHT_WORDS <= 64 || v < n_fast)
+                        {
+#pragma unroll
+                            for (int k = 0; k < 4; k += 1) lw[k] = readlane64(src, lane0 + off + k);
+                        }
+                        else
+                        {
+                            const uint64_t *lp = p_s + (uint64_t)v * vw + off;
+#pragma unroll
+                            for (int k = 0; k < 4; k += 1) lw[k] = readlane64(lp[k], 0);
+                        }
+                        if (!((uint32_t)(lw[0] >> 16) & FLAG_VISIBLE)) continue;
+                        const uint32_t i_em = (uint32_t)(lw[0] & 0xFFFFu);
+                        const double c = word_as_double(lw[1]), a_in = word_as_double(lw[2]), spec = word_as_double(lw[3]);
+#pragma unroll
+                        for (int k = 0; k < NSETS; k += 1)
+                        {
+                            double reflectance = diffuse_pi[k] * a_in + 0.0;
+                            reflectance = (glossy[k] * spec) * a_in + reflectance;
+                            contribution[k] = contribution[k] + reflectance;                      /* :323 */
+                            contribution[k] = contribution[k] * spd_at(table, S, i_em, lam_c[k]); /* :324 */
+                            contribution[k] = contribution[k] * c;                                /* :326-327 */
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NSETS; k += 1)
+                    {
+                        dst[k] = dst[k] + throughput[k] * contribution[k]; /* :461-462 */
+                        double reflectance = diffuse_pi[k] * s_a_in + 0.0;
+                        reflectance = (glossy[k] * s_spec) * s_a_in + reflectance;
+                        reflectance = reflectance * dir_pdf;         /* :468 */
+                        throughput[k] = throughput[k] * reflectance; /* :469 */
+                    }
+                    continue;
+                }
+
+                /* every other material: the general BDSF list */
+                double diffuse[NSETS], glossy[NSETS], mirror[NSETS], ir[NSETS], tr[NSETS], te[NSETS];
 #pragma unroll
                 for (int k = 0; k < NSETS; k += 1)
                 {
-                    if (SPDS_IN_LDS)
-                    {
-                        const double *t = lds;
-                        diffuse[k] = spd_at(t, S, i_diffuse, lam_c[k]); glossy[k] = spd_at(t, S, i_glossy, lam_c[k]);
-                        mirror[k] = spd_at(t, S, i_mirror, lam_c[k]);   ir[k] = spd_at(t, S, i_ir, lam_c[k]);
-                        tr[k] = spd_at(t, S, i_tr, lam_c[k]);           te[k] = spd_at(t, S, i_te, lam_c[k]);
-                    }
-                    else
-                    {
-                        const double *t = sc.spds;
-                        diffuse[k] = spd_at(t, S, i_diffuse, lam_c[k]); glossy[k] = spd_at(t, S, i_glossy, lam_c[k]);
-                        mirror[k] = spd_at(t, S, i_mirror, lam_c[k]);   ir[k] = spd_at(t, S, i_ir, lam_c[k]);
-                        tr[k] = spd_at(t, S, i_tr, lam_c[k]);           te[k] = spd_at(t, S, i_te, lam_c[k]);
-                    }
-                    contribution[k] = 0.0;
+                    diffuse[k] = spd_at(table, S, i_diffuse, lam_c[k]); glossy[k] = spd_at(table, S, i_glossy, lam_c[k]);
+                    mirror[k] = spd_at(table, S, i_mirror, lam_c[k]);   ir[k] = spd_at(table, S, i_ir, lam_c[k]);
+                    tr[k] = spd_at(table, S, i_tr, lam_c[k]);           te[k] = spd_at(table, S, i_te, lam_c[k]);
                 }
-                /* direct_light_contribution, :272-332 */
-                for (uint32_t l = 0; l < sp.n_lights; l += 1)
+                for (uint32_t l = 0; l < sp.n_lights; l += 1) /* direct_light_contribution, :272-332 */
                 {
                     const uint32_t off = REC_VERTEX_WORDS + l * REC_LIGHT_WORDS;
                     uint64_t lw[REC_LIGHT_WORDS];
@@ -957,23 +1012,21 @@ __global__ __launch_bounds__(SHADE_BLOCK) void drt_shade_kernel(DevScene sc, Sha
                     {
                         double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse[k], glossy[k], mirror[k], ir[k], tr[k], te[k], on_dot,
                                                                 word_as_double(lw[2]), word_as_double(lw[3]), word_as_double(lw[4]),
-                                                                word_as_double(lw[5]), lflags, inv_pi);
-                        const double em = SPDS_IN_LDS ? spd_at((const double *)lds, S, i_em, lam_c[k]) : spd_at(sc.spds, S, i_em, lam_c[k]);
-                        contribution[k] = contribution[k] + reflectance; /* :323 */
-                        contribution[k] = contribution[k] * em;          /* :324 */
-                        contribution[k] = contribution[k] * c;           /* :326-327 */
+                                                                word_as_double(lw[5]), lflags);
+                        contribution[k] = contribution[k] + reflectance;                      /* :323 */
+                        contribution[k] = contribution[k] * spd_at(table, S, i_em, lam_c[k]); /* :324 */
+                        contribution[k] = contribution[k] * c;                                /* :326-327 */
                     }
                 }
-                const double s_a_in = word_as_double(readlane64(src, lane0 + 5)), s_spec = word_as_double(readlane64(src, lane0 + 6));
                 const double s_mn = word_as_double(readlane64(src, lane0 + 7)), s_ct = word_as_double(readlane64(src, lane0 + 8));
 #pragma unroll
                 for (int k = 0; k < NSETS; k += 1)
                 {
                     dst[k] = dst[k] + throughput[k] * contribution[k]; /* :461-462 */
                     double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse[k], glossy[k], mirror[k], ir[k], tr[k], te[k], on_dot,
-                                                            s_a_in, s_spec, s_mn, s_ct, sflags, inv_pi);
-                    reflectance = reflectance * dir_pdf;            /* :468 */
-                    throughput[k] = throughput[k] * reflectance;    /* :469 */
+                                                            s_a_in, s_spec, s_mn, s_ct, sflags);
+                    reflectance = reflectance * dir_pdf;         /* :468 */
+                    throughput[k] = throughput[k] * reflectance; /* :469 */
                 }
             }
             const double denom = (double)(sp.first_sample + s + 1);
@@ -1066,6 +1119,17 @@ __global__ void drt_selftest_kernel(int op, const double *a, const double *b, do
             double v = 0.0;
             for (int k = 0; k < 4; k += 1) v = drt_rng(rs, draws);
             out[i] = v;
+            break;
+        }
+        case 5: /* issue-cost probes: a dependent f64 FMA chain on all lanes (5) or on lanes 0-4 of each wave only (6) */
+        case 6:
+        {
+            double x = a[i], y = b[i];
+            if (op == 5 || (threadIdx.x & 63u) < 5u)
+            {
+                for (int k = 0; k < 65536; k += 1) x = __builtin_fma(x, y, 1.0e-3);
+            }
+            out[i] = x;
             break;
         }
         default: out[i] = 0.0; break;

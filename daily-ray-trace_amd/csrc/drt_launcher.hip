@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -175,6 +176,16 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene)
         lights[(size_t)LF_PDF * n_lights + l] = pdf;
     }
 
+    std::vector<double> spds(scene->spds, scene->spds + (size_t)scene->num_spds * S);
+    std::map<int32_t, uint32_t> diffuse_pi_row;
+    /* the zero row is appended last; derived rows go between: reserve its index now */
+    uint32_t n_diffuse = 0;
+    {
+        std::map<int32_t, int> seen;
+        for (uint32_t i = 0; i < scene->num_materials; i += 1)
+            if (scene->materials[i].diffuse_spd >= 0 && !seen[scene->materials[i].diffuse_spd]++) n_diffuse += 1;
+    }
+    const uint32_t zero_row = scene->num_spds + n_diffuse;
     std::vector<DevMaterial> mats(scene->num_materials);
     for (uint32_t i = 0; i < scene->num_materials; i += 1)
     {
@@ -188,8 +199,24 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene)
         const int32_t idx[6] = {m.emission_spd, m.diffuse_spd, m.glossy_spd, m.mirror_spd, m.refract_spd, m.extinct_spd};
         for (int k = 0; k < 6; k += 1)
             if (idx[k] >= (int32_t)scene->num_spds) return fail(-2, "material %u: SPD index out of range", i);
-        dm.emission_spd = m.emission_spd; dm.diffuse_spd = m.diffuse_spd; dm.glossy_spd = m.glossy_spd;
-        dm.mirror_spd = m.mirror_spd; dm.refract_spd = m.refract_spd; dm.extinct_spd = m.extinct_spd;
+        /* device rows: scene rows as they are; a missing spectrum -> the all-zero row; diffuse -> its derived
+         * diffuse * (1/PI) row (bp_diffuse_bdsf's first product, src/bdsf.c:107, is a per-material constant) */
+        auto row = [&](int32_t i) { return i >= 0 ? i : (int32_t)zero_row; };
+        dm.emission_spd = row(m.emission_spd); dm.glossy_spd = row(m.glossy_spd);
+        dm.mirror_spd = row(m.mirror_spd); dm.refract_spd = row(m.refract_spd); dm.extinct_spd = row(m.extinct_spd);
+        dm.diffuse_spd = (int32_t)zero_row;
+        if (m.diffuse_spd >= 0)
+        {
+            auto it = diffuse_pi_row.find(m.diffuse_spd);
+            if (it == diffuse_pi_row.end())
+            {
+                const double inv_pi = 1.0 / DRT_PI;
+                uint32_t r = (uint32_t)(spds.size() / S);
+                for (uint32_t k = 0; k < S; k += 1) spds.push_back(scene->spds[(size_t)m.diffuse_spd * S + k] * inv_pi);
+                it = diffuse_pi_row.emplace(m.diffuse_spd, r).first;
+            }
+            dm.diffuse_spd = (int32_t)it->second;
+        }
         dm.shininess = m.shininess;
         dm.roughness = m.roughness;
         if (m.refract_spd >= 0)
@@ -208,9 +235,11 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene)
             if (b == DRT_BDSF_fs_dielectric_transmittance_bdsf) dm.needs |= NEED_EQT;
             if (b == DRT_BDSF_ct_conductor_bdsf) dm.needs |= NEED_CT;
         }
+        if (dm.num_bdsfs == 2 && dm.bdsfs[0] == DRT_BDSF_bp_diffuse_bdsf && dm.bdsfs[1] == DRT_BDSF_bp_glossy_bdsf) dm.vertex_flags = FLAG_PLASTIC;
         if (!m.is_black_body && dm.dir_func >= DRT_NUM_DIRFS) return fail(-2, "material %u: unknown dir_func id %u", i, dm.dir_func);
     }
-    std::vector<double> spds(scene->spds, scene->spds + (size_t)scene->num_spds * S);
+    spds.resize((size_t)(zero_row + 1) * S, 0.0); /* + the all-zero row */
+    d.n_spd = zero_row + 1;
 
     int rc;
     if ((rc = upload(ctx, surf, &d.surf))) return rc;
@@ -232,7 +261,7 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene)
     ctx->trace_lds = trace_lds_bytes(n_surf, n_lights, scene->num_materials);
     ctx->scene_in_lds = ctx->trace_lds <= 64 * 1024;
     if (!ctx->scene_in_lds) ctx->trace_lds = 0;
-    ctx->spds_in_lds = (size_t)scene->num_spds * S * 8 <= 64 * 1024;
+    ctx->spds_in_lds = (size_t)d.n_spd * S * 8 <= 64 * 1024;
     return 0;
 }
 
@@ -305,7 +334,7 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     ctx->vertex_words = 16;
     while (ctx->vertex_words < REC_VERTEX_WORDS + REC_LIGHT_WORDS * ctx->dsc.n_lights) ctx->vertex_words *= 2;
     ctx->path_words = ctx->vertex_words * params->max_depth;
-    if (scene->num_spds >= REC_NO_SPD) return fail(-2, "too many SPDs for the 16-bit record indices");
+    if (ctx->dsc.n_spd >= 0xFFFFu) return fail(-2, "too many SPDs for the 16-bit record indices");
     if (S > 64 * SHADE_MAX_SETS) return fail(-2, "more than %d wavelengths", 64 * SHADE_MAX_SETS);
 
     /* batch: enough paths in flight to fill the chip many times over, bounded record memory */
@@ -348,7 +377,7 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     if (const char *e = getenv("DRT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e)); /* tuning knob */
     ctx->trace_grid_cap = prop.multiProcessorCount * per_cu;
     /* shade kernel LDS: SPD tables + two record buffers per wave */
-    ctx->shade_lds = ctx->spds_in_lds ? (size_t)scene->num_spds * S * 8 : 0;
+    ctx->shade_lds = ctx->spds_in_lds ? (size_t)ctx->dsc.n_spd * S * 8 : 0;
     int s_per_cu = 0;
     switch ((S + 63) / 64)
     {
@@ -673,9 +702,19 @@ extern "C" int drt_selftest_arith(int device, int op, const double *a, const dou
     HIP_TRY(hipMalloc((void **)&dout, std::max<size_t>(out_n, 1) * 8));
     HIP_TRY(hipMemcpy(da, a, n * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(db, b, n * 8, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, 0));
     hipLaunchKernelGGL(drt_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, da, db, dout, n);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e1, 0));
     HIP_TRY(hipDeviceSynchronize());
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (getenv("DRT_VERBOSE")) fprintf(stderr, "drt_selftest_arith op %d n %llu: %.3f ms\n", op, (unsigned long long)n, ms);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     HIP_TRY(hipMemcpy(out, dout, out_n * 8, hipMemcpyDeviceToHost));
     (void)hipFree(da);
     (void)hipFree(db);
