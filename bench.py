@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--batch", type=int, default=0, help="samples per kernel pair (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal only: all ranks use GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -100,11 +102,16 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with %d processes" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     W = H = args.size
     scene_file = os.path.join(REPO, "scenes", "cornell_plane_light.scn")
@@ -122,6 +129,8 @@ def main():
     stream = torch.cuda.current_stream()
     r.set_stream(stream.cuda_stream)
 
+    staging = args.backend != "nccl"  # gloo rehearsal: collectives on host copies
+
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -138,7 +147,8 @@ def main():
             t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
             t0.record()
             for t, c in zip(film, (S + 1, S, S)):
-                drt_dist.gather_tiles(t.reshape(tile_h, W, c), H, W, rank, world)
+                tile = t.reshape(tile_h, W, c)
+                drt_dist.gather_tiles(tile.cpu() if staging else tile, H, W, rank, world)
             t1.record()
             torch.cuda.synchronize()
             gather_ms[0] += t0.elapsed_time(t1)
@@ -158,7 +168,7 @@ def main():
     st1 = r.stats()
     batch_spp = r.batch_spp()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if staging else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

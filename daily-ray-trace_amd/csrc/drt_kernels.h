@@ -53,6 +53,18 @@ enum
     NEED_CT     = 8u  /* ct_conductor_bdsf: half-vector cosine + GGX coefficient */
 };
 
+/* Bounding-volume hierarchy over the surfaces of a large scene. It only PRUNES the surface
+ * scan: leaves call the same intersectors, and the closest hit is the minimum distance with the lowest surface
+ * index on ties -- exactly what the reference's linear scan with its strict `<` returns
+ * (src/daily_ray_trace.c:340-364) -- so hit indices do not change by a bit. Boxes are padded, so a surface whose
+ * COMPUTED distance is finite always lies inside its boxes. */
+struct BvhNode
+{
+    double  lo[2][3], hi[2][3]; /* the two children's boxes */
+    int32_t child[2];           /* inner child: node index; leaf child: first slot in bvh_prims */
+    int32_t count[2];           /* 0: inner child, > 0: leaf with that many surfaces, < 0: no child */
+};
+
 struct DevMaterial
 {
     uint32_t is_black_body, is_emissive, num_bdsfs, dir_func;
@@ -78,8 +90,9 @@ struct DevScene
     const uint32_t    *light_type; /* [n_lights] */
     const uint32_t    *light_mat;  /* [n_lights] material of the emissive surface */
     const DevMaterial *mats;       /* [n_mat] */
-    const double      *spds;       /* [n_spd][S] */
-    const double      *inv_pi_diffuse; /* unused slot kept for layout stability */
+    const double      *spds;       /* [n_spd][S]: scene rows, derived diffuse/pi rows, one zero row */
+    const BvhNode     *bvh_nodes;  /* NULL: scan every surface */
+    const uint32_t    *bvh_prims;  /* surface indices, grouped by leaf */
 };
 
 struct DevCamera
@@ -147,6 +160,8 @@ struct SceneView /* pointers into LDS (or HBM when the scene does not fit) */
     const double      *lights;
     const uint32_t    *light_type, *light_mat;
     const DevMaterial *mats;
+    const BvhNode     *bvh_nodes;
+    const uint32_t    *bvh_prims;
     uint32_t           n_surf, n_lights;
 };
 
@@ -162,12 +177,116 @@ __device__ __forceinline__ double surface_distance(const SceneView &sv, uint32_t
                       sv.surf[SF_ULEN * sv.n_surf + i], sv.surf[SF_VLEN * sv.n_surf + i]);
 }
 
+#define BVH_STACK 48
+
+/* ray vs padded box: entry distance, or a negative number when the box is missed / behind the ray */
+__device__ __forceinline__ double bvh_box_entry(const BvhNode &n, int c, V3 o, V3 inv_d)
+{
+    double t0x = (n.lo[c][0] - o.x) * inv_d.x, t1x = (n.hi[c][0] - o.x) * inv_d.x;
+    double t0y = (n.lo[c][1] - o.y) * inv_d.y, t1y = (n.hi[c][1] - o.y) * inv_d.y;
+    double t0z = (n.lo[c][2] - o.z) * inv_d.z, t1z = (n.hi[c][2] - o.z) * inv_d.z;
+    double tmin = __builtin_fmax(__builtin_fmax(__builtin_fmin(t0x, t1x), __builtin_fmin(t0y, t1y)), __builtin_fmin(t0z, t1z));
+    double tmax = __builtin_fmin(__builtin_fmin(__builtin_fmax(t0x, t1x), __builtin_fmax(t0y, t1y)), __builtin_fmax(t0z, t1z));
+    if (!(tmax >= 0.0) || !(tmin <= tmax)) return -1.0;
+    return tmin > 0.0 ? tmin : 0.0;
+}
+
+/* closest hit through the hierarchy: min distance, lowest index on ties */
+__device__ __forceinline__ void bvh_closest(const SceneView &sv, V3 o, V3 d, double &min_dist, int &index)
+{
+    V3 inv_d = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    int stack[BVH_STACK];
+    int sp = 0;
+    int node = 0;
+    for (;;)
+    {
+        const BvhNode &n = sv.bvh_nodes[node];
+        int next = -1;
+        double next_t = 0.0;
+        for (int c = 0; c < 2; c += 1)
+        {
+            int cnt = n.count[c];
+            if (cnt < 0) continue;
+            double t = bvh_box_entry(n, c, o, inv_d);
+            if (t < 0.0 || t > min_dist) continue;
+            if (cnt > 0)
+            {
+                for (int k = 0; k < cnt; k += 1)
+                {
+                    uint32_t i = sv.bvh_prims[n.child[c] + k];
+                    double dist = surface_distance(sv, i, sv.surf_type[i], o, d);
+                    if (dist < min_dist || (dist == min_dist && (int)i < index))
+                    {
+                        min_dist = dist;
+                        index = (int)i;
+                    }
+                }
+            }
+            else if (next < 0)
+            {
+                next = n.child[c];
+                next_t = t;
+            }
+            else if (sp < BVH_STACK)
+            {
+                /* two inner children: descend into the nearer one first */
+                if (t < next_t)
+                {
+                    stack[sp++] = next;
+                    next = n.child[c];
+                    next_t = t;
+                }
+                else stack[sp++] = n.child[c];
+            }
+        }
+        if (next >= 0) node = next;
+        else if (sp > 0) node = stack[--sp];
+        else break;
+    }
+}
+
+/* any surface nearer than vis_dist? (the shadow test; order does not matter for a yes/no answer) */
+__device__ __forceinline__ bool bvh_occluded(const SceneView &sv, V3 o, V3 d, double vis_dist)
+{
+    V3 inv_d = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    int stack[BVH_STACK];
+    int sp = 0;
+    int node = 0;
+    for (;;)
+    {
+        const BvhNode &n = sv.bvh_nodes[node];
+        int next = -1;
+        for (int c = 0; c < 2; c += 1)
+        {
+            int cnt = n.count[c];
+            if (cnt < 0) continue;
+            double t = bvh_box_entry(n, c, o, inv_d);
+            if (t < 0.0 || !(t < vis_dist)) continue;
+            if (cnt > 0)
+            {
+                for (int k = 0; k < cnt; k += 1)
+                {
+                    uint32_t i = sv.bvh_prims[n.child[c] + k];
+                    if (surface_distance(sv, i, sv.surf_type[i], o, d) < vis_dist) return true;
+                }
+            }
+            else if (next < 0) next = n.child[c];
+            else if (sp < BVH_STACK) stack[sp++] = n.child[c];
+        }
+        if (next >= 0) node = next;
+        else if (sp > 0) node = stack[--sp];
+        else break;
+    }
+    return false;
+}
+
 /* points_mutually_visible, src/daily_ray_trace.c:238-270 */
 __device__ __forceinline__ bool points_mutually_visible(const SceneView &sv, V3 p0, V3 p1)
 {
     V3 dir = v_normalise(v_sub(p1, p0));
     V3 o = v_sum(p0, v_mul(dir, DRT_VIS_FUDGE));
     double vis_dist = v_length(v_sub(p1, o)) - DRT_VIS_FUDGE;
+    if (sv.bvh_nodes) return !bvh_occluded(sv, o, dir, vis_dist);
     bool visible = true;
     for (uint32_t i = 0; i < sv.n_surf; i += 1)
     {
@@ -194,15 +313,19 @@ __device__ __forceinline__ void find_ray_intersection(const SceneView &sv, const
     double min_dist = DRT_INF;
     int index = -1;
     ro = v_sum(ro, v_mul(rd, DRT_VIS_FUDGE));
-    for (uint32_t i = 0; i < sv.n_surf; i += 1)
+    if (sv.bvh_nodes) bvh_closest(sv, ro, rd, min_dist, index);
+    else
     {
-        uint32_t type = sv.surf_type[i];
-        if (type != DRT_GEO_SPHERE && type != DRT_GEO_PLANE) continue;
-        double dist = surface_distance(sv, i, type, ro, rd);
-        if (dist < min_dist)
+        for (uint32_t i = 0; i < sv.n_surf; i += 1)
         {
-            min_dist = dist;
-            index = (int)i;
+            uint32_t type = sv.surf_type[i];
+            if (type != DRT_GEO_SPHERE && type != DRT_GEO_PLANE) continue;
+            double dist = surface_distance(sv, i, type, ro, rd);
+            if (dist < min_dist)
+            {
+                min_dist = dist;
+                index = (int)i;
+            }
         }
     }
     ip.index = index;
@@ -468,6 +591,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
         sv.light_type = l_u32 + 2 * sc.n_surf;
         sv.light_mat = l_u32 + 2 * sc.n_surf + sc.n_lights;
         sv.mats = l_mats;
+        sv.bvh_nodes = nullptr; /* a scene that fits LDS is scanned whole */
+        sv.bvh_prims = nullptr;
     }
     else
     {
@@ -478,6 +603,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
         sv.light_type = sc.light_type;
         sv.light_mat = sc.light_mat;
         sv.mats = sc.mats;
+        sv.bvh_nodes = sc.bvh_nodes;
+        sv.bvh_prims = sc.bvh_prims;
     }
 
     const uint32_t lane = threadIdx.x & 63u;

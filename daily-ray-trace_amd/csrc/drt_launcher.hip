@@ -58,7 +58,7 @@ struct drt_context
     unsigned long long *d_counters = nullptr; /* DRT_NUM_COUNTERS stats + 1 work counter */
     double   *d_xyz = nullptr;
 
-    bool   scene_in_lds = true, spds_in_lds = true;
+    bool   scene_in_lds = true, spds_in_lds = true, use_bvh = false;
     size_t trace_lds = 0, shade_lds = 0;
     int    trace_grid_cap = 0, shade_grid_cap = 0;
     uint64_t n_pix = 0;
@@ -66,7 +66,6 @@ struct drt_context
     std::vector<hipEvent_t> ev; /* triples: trace start, trace end / shade start, shade end */
     size_t ev_used = 0;
     double trace_ms = 0.0, shade_ms = 0.0;
-    drt_stats host_stats{};
 };
 
 static size_t trace_lds_bytes(uint32_t n_surf, uint32_t n_lights, uint32_t n_mat)
@@ -94,6 +93,109 @@ static V3 hv(const double a[3]) { V3 r; r.x = a[0]; r.y = a[1]; r.z = a[2]; retu
 /* host-side twins of the device vector ops used for per-surface constants (same IEEE ops) */
 static double h_dot(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 static double h_length(const double a[3]) { return std::sqrt(h_dot(a, a)); }
+
+/* ---- BVH over the surfaces of a large scene (host build: median split, padded boxes) ---- */
+struct BuildPrim
+{
+    double   lo[3], hi[3], c[3];
+    uint32_t idx;
+};
+
+static void prim_bounds(const drt_surface &s, double lo[3], double hi[3])
+{
+    for (int k = 0; k < 3; k += 1)
+    {
+        if (s.type == DRT_GEO_SPHERE)
+        {
+            lo[k] = s.position[k] - std::fabs(s.radius);
+            hi[k] = s.position[k] + std::fabs(s.radius);
+        }
+        else
+        {
+            double c0 = s.position[k], c1 = c0 + s.u[k], c2 = c0 + s.v[k], c3 = c0 + s.u[k] + s.v[k];
+            lo[k] = std::min(std::min(c0, c1), std::min(c2, c3));
+            hi[k] = std::max(std::max(c0, c1), std::max(c2, c3));
+        }
+        /* pad: a hit the intersector COMPUTES (rounding included) must stay inside the box */
+        double pad = 1e-5 + 1e-9 * std::max(std::fabs(lo[k]), std::fabs(hi[k]));
+        lo[k] -= pad;
+        hi[k] += pad;
+    }
+}
+
+struct BvhBuilder
+{
+    std::vector<BuildPrim> prims;
+    std::vector<BvhNode>   nodes;
+    std::vector<uint32_t>  order;
+    static const int LEAF = 4;
+
+    void bounds(size_t b, size_t e, double lo[3], double hi[3]) const
+    {
+        for (int k = 0; k < 3; k += 1) { lo[k] = HUGE_VAL; hi[k] = -HUGE_VAL; }
+        for (size_t i = b; i < e; i += 1)
+            for (int k = 0; k < 3; k += 1)
+            {
+                lo[k] = std::min(lo[k], prims[i].lo[k]);
+                hi[k] = std::max(hi[k], prims[i].hi[k]);
+            }
+    }
+    /* fills child slot c of node `parent` with the subtree over prims [b, e) */
+    void set_child(int parent, int c, size_t b, size_t e)
+    {
+        double lo[3], hi[3];
+        bounds(b, e, lo, hi);
+        for (int k = 0; k < 3; k += 1) { nodes[parent].lo[c][k] = lo[k]; nodes[parent].hi[c][k] = hi[k]; }
+        if (e - b <= (size_t)LEAF)
+        {
+            nodes[parent].child[c] = (int32_t)order.size();
+            nodes[parent].count[c] = (int32_t)(e - b);
+            for (size_t i = b; i < e; i += 1) order.push_back(prims[i].idx);
+            return;
+        }
+        int me = (int)nodes.size();
+        nodes.push_back(BvhNode());
+        nodes[parent].child[c] = me;
+        nodes[parent].count[c] = 0;
+        split(me, b, e);
+    }
+    void split(int node, size_t b, size_t e)
+    {
+        double clo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, chi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+        for (size_t i = b; i < e; i += 1)
+            for (int k = 0; k < 3; k += 1)
+            {
+                clo[k] = std::min(clo[k], prims[i].c[k]);
+                chi[k] = std::max(chi[k], prims[i].c[k]);
+            }
+        int axis = 0;
+        for (int k = 1; k < 3; k += 1) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+        size_t mid = (b + e) / 2;
+        std::nth_element(prims.begin() + b, prims.begin() + mid, prims.begin() + e,
+                         [axis](const BuildPrim &x, const BuildPrim &y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx); });
+        set_child(node, 0, b, mid);
+        set_child(node, 1, mid, e);
+    }
+    void build(const drt_scene *scene)
+    {
+        for (uint32_t i = 0; i < scene->num_surfaces; i += 1)
+        {
+            const drt_surface &s = scene->surfaces[i];
+            if (s.type != DRT_GEO_SPHERE && s.type != DRT_GEO_PLANE) continue; /* points are never intersected */
+            BuildPrim p;
+            prim_bounds(s, p.lo, p.hi);
+            for (int k = 0; k < 3; k += 1) p.c[k] = 0.5 * (p.lo[k] + p.hi[k]);
+            p.idx = i;
+            prims.push_back(p);
+        }
+        nodes.push_back(BvhNode());
+        nodes[0].count[0] = nodes[0].count[1] = -1;
+        nodes[0].child[0] = nodes[0].child[1] = 0;
+        if (prims.empty()) return;
+        if (prims.size() <= (size_t)LEAF) set_child(0, 0, 0, prims.size());
+        else split(0, 0, prims.size());
+    }
+};
 
 static int build_device_scene(drt_context *ctx, const drt_scene *scene)
 {
@@ -250,7 +352,6 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene)
     if ((rc = upload(ctx, lmat, &d.light_mat))) return rc;
     if ((rc = upload(ctx, mats, &d.mats))) return rc;
     if ((rc = upload(ctx, spds, &d.spds))) return rc;
-    d.inv_pi_diffuse = nullptr;
 
     ctx->cmf_rw = scene->cmf_rw; ctx->cmf_x = scene->cmf_x; ctx->cmf_y = scene->cmf_y; ctx->cmf_z = scene->cmf_z;
     ctx->interval = scene->wavelength_interval;
@@ -259,7 +360,20 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene)
 
     /* LDS budgets: keep the scene in LDS when it leaves room for >= 2 workgroups per CU */
     ctx->trace_lds = trace_lds_bytes(n_surf, n_lights, scene->num_materials);
-    ctx->scene_in_lds = ctx->trace_lds <= 64 * 1024;
+    /* small scenes: whole scan out of LDS; large scenes: tables stay in HBM/L2 and a BVH prunes the scan */
+    ctx->scene_in_lds = ctx->trace_lds <= 64 * 1024 && n_surf <= 96 && !getenv("DRT_FORCE_BVH");
+    if (getenv("DRT_NO_BVH")) ctx->use_bvh = false; /* tuning knob: brute-force scan from HBM */
+    else ctx->use_bvh = !ctx->scene_in_lds;
+    d.bvh_nodes = nullptr;
+    d.bvh_prims = nullptr;
+    if (ctx->use_bvh)
+    {
+        BvhBuilder bb;
+        bb.build(scene);
+        if (bb.order.empty()) bb.order.push_back(0);
+        if ((rc = upload(ctx, bb.nodes, &d.bvh_nodes))) return rc;
+        if ((rc = upload(ctx, bb.order, &d.bvh_prims))) return rc;
+    }
     if (!ctx->scene_in_lds) ctx->trace_lds = 0;
     ctx->spds_in_lds = (size_t)d.n_spd * S * 8 <= 64 * 1024;
     return 0;
@@ -312,6 +426,9 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
 {
     if (!scene || !camera || !params) return fail(-1, "null argument");
     if (params->tile_w == 0 || params->tile_h == 0 || params->max_depth == 0) return fail(-1, "empty tile or zero depth");
+    if (params->mode != DRT_MODE_SPECTRAL) return fail(-1, "only DRT_MODE_SPECTRAL (the reference's full spectral film) is implemented");
+    if ((uint64_t)params->x0 + params->tile_w > params->width || (uint64_t)params->y0 + (uint64_t)(params->tile_h - 1) * (params->row_stride ? params->row_stride : 1) >= params->height)
+        return fail(-1, "tile does not fit the %ux%u image", params->width, params->height);
     ctx->params = *params;
     if (ctx->params.row_stride == 0) ctx->params.row_stride = 1;
     ctx->device = params->device;

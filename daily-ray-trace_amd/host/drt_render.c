@@ -102,6 +102,15 @@ int render_image_ex(config_arguments *config, const drt_host_options *opt, drt_s
     int w1 = drt_host_write_spd(config->variance_spd, width, height, S, 0, scene->min_wavelength, scene->wavelength_interval, dst_vars);
     int w2 = drt_host_write_spd(config->average_spd, width, height, S, 0, scene->min_wavelength, scene->wavelength_interval, dst_avgs);
     if (w0 || w1 || w2) fprintf(stderr, "render_image: could not write one of the .spd outputs\n");
+    /* post-process like the reference's main(): each .spd -> linear RGB -> BMP (src/win32_main.c:150-152) */
+    if (!(w0 || w1 || w2) && config->output_bmp[0])
+    {
+        const f64 *cmf = scene->spds + (size_t)scene->cmf_rw * S; /* rows rw, x, y, z are adjacent (host/drt_scene.c) */
+        int b0 = drt_host_spd_file_to_bmp(config->output_spd, config->output_bmp, cmf);
+        int b1 = config->average_bmp[0] ? drt_host_spd_file_to_bmp(config->average_spd, config->average_bmp, cmf) : 0;
+        int b2 = config->variance_bmp[0] ? drt_host_spd_file_to_bmp(config->variance_spd, config->variance_bmp, cmf) : 0;
+        if (b0 || b1 || b2) fprintf(stderr, "render_image: could not write one of the .bmp outputs\n");
+    }
     if (stats_out) *stats_out = stats;
     free(dst_vars);
     free(dst_avgs);

@@ -141,7 +141,7 @@ typedef struct drt_camera
 enum
 {
     DRT_MODE_SPECTRAL = 0, /* film = sum(+filter), mean, variance per wavelength (the reference's output) */
-    DRT_MODE_XYZ      = 1  /* additionally keep only XYZ; reported as a different mode */
+    DRT_MODE_XYZ      = 1  /* reserved: XYZ-only film (not implemented; drt_create rejects it) */
 };
 
 /*

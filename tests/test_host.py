@@ -169,3 +169,38 @@ def test_product_does_not_touch_the_oracle():
                         if re.search(pat, text, re.M):
                             bad.append((os.path.join(dirpath, f), pat))
     assert bad == [], bad
+
+
+def test_spd_to_bmp_postprocess(tmp_path, golden_dir):
+    """N2: .spd -> linear RGB -> 32-bit bottom-up BMP, with the reference's spectrum_to_rgb_f64 as known answer."""
+    H = pydrt.host_lib()
+    g = np.load(os.path.join(golden_dir, "unit_spectral.npz"), allow_pickle=False)
+    S = g["tables"].shape[1]
+    cmf = np.ascontiguousarray(g["tables"][0:4])
+    f64p = C.POINTER(C.c_double)
+    H.drt_host_spectrum_to_rgb.argtypes = [f64p, C.c_uint32, C.c_double, f64p, f64p]
+    rgb = np.zeros(3)
+    for i in range(len(g["rgbs"])):
+        H.drt_host_spectrum_to_rgb(cmf.ctypes.data_as(f64p), S, 5.0, g["rgb_spd"][i].copy().ctypes.data_as(f64p), rgb.ctypes.data_as(f64p))
+        assert np.array_equal(rgb, g["rgb_back"][i])  # == the compiled reference's spectrum_to_rgb_f64
+    # a 3x2 film with filter sums: pixel i carries spectrum i (pre-multiplied by the filter value 2)
+    w, h = 3, 2
+    film = np.zeros((w * h, S + 1))
+    film[:, :S] = g["rgb_spd"][:6] * 2.0
+    film[:, S] = 2.0
+    H.drt_host_write_spd.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, f64p]
+    spd = str(tmp_path / "o.spd").encode()
+    bmp = str(tmp_path / "o.bmp").encode()
+    assert H.drt_host_write_spd(spd, w, h, S, 1, 380.0, 5.0, film.ctypes.data_as(f64p)) == 0
+    H.drt_host_spd_file_to_bmp.argtypes = [C.c_char_p, C.c_char_p, f64p]
+    assert H.drt_host_spd_file_to_bmp(spd, bmp, cmf.ctypes.data_as(f64p)) == 0
+    raw = open(bmp, "rb").read()
+    assert len(raw) == 14 + 40 + w * h * 4 and raw[:2] == b"BM"
+    size, off = struct.unpack_from("<I4xI", raw, 2)
+    assert (size, off) == (len(raw), 54)
+    hdr = struct.unpack_from("<IiiHHIIiiII", raw, 14)
+    assert hdr[0:3] == (40, w, h) and hdr[4] == 32 and hdr[7:9] == (3780, 3780)
+    px = np.frombuffer(raw, dtype=np.uint8, offset=54).reshape(w * h, 4)
+    expect = (np.clip(g["rgb_back"][:6], 0.0, 1.0) * 255.0).astype(np.uint8)  # clamp, truncate, no gamma
+    assert np.array_equal(px[:, 2], expect[:, 0]) and np.array_equal(px[:, 1], expect[:, 1]) and np.array_equal(px[:, 0], expect[:, 2])
+    assert np.all(px[:, 3] == 255)
