@@ -26,6 +26,8 @@ RENDER_CASES = {
     "downward": ("cornell_downward.scn", 24, 24, 2, 4, 1, pydrt.FILM_SAMPLE_RANDOM),  # legacy, roll 180
     "lights": ("test_lights.scn", 32, 32, 4, 6, 5, pydrt.FILM_SAMPLE_RANDOM),  # plane + sphere + point light
     "lens": ("test_lens.scn", 24, 24, 3, 4, 2, pydrt.FILM_SAMPLE_RANDOM),  # thin-lens camera
+    "many_lights": ("test_many_lights.scn", 24, 24, 2, 5, 4, pydrt.FILM_SAMPLE_RANDOM),  # 12 lights: vertex records wider than a 64-word register
+    "deep_paths": ("cornell_large_box.scn", 16, 16, 2, 40, 6, pydrt.FILM_SAMPLE_RANDOM),  # more vertices than the shade kernel prefetches
     "spheres_1500": ("@spheres:1500", 32, 32, 2, 6, 9, pydrt.FILM_SAMPLE_RANDOM),  # config 5 generator, reduced
 }
 
