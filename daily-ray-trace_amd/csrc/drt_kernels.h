@@ -827,7 +827,9 @@ struct ShadeParams
 {
     uint64_t n_pix;
     uint32_t n_samples, first_sample, vertex_words, path_words;
-    uint32_t n_lights, batch, pad0, pad1;
+    uint32_t n_lights, batch;
+    uint32_t tail_first, tail_count; /* wavelengths [tail_first, tail_first + tail_count) go through the packed tail pass (0: none) */
+    uint32_t chunk, pad0;            /* pixels per work chunk (= tail group size when there is a tail) */
 };
 
 __device__ __forceinline__ double word_as_double(uint64_t w) { return __longlong_as_double((long long)w); }
@@ -921,7 +923,7 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
  * into LDS once) and draw chunks of pixels from a global counter, because pixel cost varies.
  */
 #define SHADE_PREFETCH_REGS 4 /* 64-word registers per path: 256 record words are prefetched, deeper paths fall back */
-#define SHADE_PIXEL_CHUNK 16
+#define SHADE_PIXEL_CHUNK 16 /* default pixels per work chunk */
 
 template <int NSETS, bool SPDS_IN_LDS>
 __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_shade_kernel(DevScene sc, ShadeParams sp, const uint64_t *__restrict__ records,
@@ -948,23 +950,21 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
     for (int k = 0; k < NSETS; k += 1)
     {
         const uint32_t lam = 64u * k + lane;
-        lam_c[k] = lam < S ? lam : 0;
+        lam_c[k] = lam < S ? lam : 0; /* lanes past the table read row element 0 and are never stored */
     }
 
-    uint64_t chunk_next = 0, chunk_end = 0; /* wave-uniform */
+    const uint32_t S_main = sp.tail_count ? sp.tail_first : S; /* wavelengths the lane-per-wavelength pass covers */
     for (;;)
     {
-        if (chunk_next >= chunk_end)
-        {
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(work_counter, (unsigned long long)SHADE_PIXEL_CHUNK);
-            base = readlane64(base, 0);
-            if (base >= sp.n_pix) break;
-            chunk_next = base;
-            chunk_end = (base + SHADE_PIXEL_CHUNK < sp.n_pix) ? base + SHADE_PIXEL_CHUNK : sp.n_pix;
-        }
-        const uint64_t pix = chunk_next;
-        chunk_next += 1;
+        /* draw the next chunk of pixels (wave-uniform) */
+        unsigned long long chunk_base = 0;
+        if (lane == 0) chunk_base = atomicAdd(work_counter, (unsigned long long)sp.chunk);
+        chunk_base = readlane64(chunk_base, 0);
+        if (chunk_base >= sp.n_pix) break;
+        const uint64_t chunk_end = (chunk_base + sp.chunk < sp.n_pix) ? chunk_base + sp.chunk : sp.n_pix;
+
+      for (uint64_t pix = chunk_base; pix < chunk_end; pix += 1)
+      {
 
         double *px = film_pixels + pix * (uint64_t)(S + 1);
         double *pa = film_avgs + pix * (uint64_t)S;
@@ -974,7 +974,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
         for (int k = 0; k < NSETS; k += 1)
         {
             const uint32_t lam = 64u * k + lane;
-            const bool active = lam < S;
+            const bool active = lam < S_main;
             f_sum[k] = active ? px[lam] : 0.0;
             f_avg[k] = active ? pa[lam] : 0.0;
             f_var[k] = active ? pv[lam] : 0.0;
@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
         for (int k = 0; k < NSETS; k += 1)
         {
             const uint32_t lam = 64u * k + lane;
-            if (lam < S)
+            if (lam < S_main)
             {
                 px[lam] = f_sum[k];
                 pa[lam] = f_avg[k];
@@ -1189,6 +1189,120 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
             }
         }
         if (lane == 0) px[S] += (double)sp.n_samples * 1.0; /* filter sum: += 1.0 per sample, :733 */
+      }
+
+        /*
+         * Tail pass. S = 69 leaves 5 wavelengths beyond the 64 lanes; giving them a second register set would
+         * cost every vector instruction again for 5 useful lanes. Instead the tails of the chunk's pixels are
+         * packed into one wave: lane = (pixel g of the chunk, tail wavelength j). Each lane replays ITS pixel's
+         * records, read per lane from HBM/L2 (the main pass just touched them), with the same per-wavelength
+         * arithmetic in the same order; lanes of different pixels may diverge on material and path length.
+         */
+        if (sp.tail_count)
+        {
+            const uint32_t R = sp.tail_count;
+            const uint32_t g = lane / R, j = lane - g * R;
+            const uint64_t pix_l = chunk_base + g;
+            const bool act = g < (uint32_t)(chunk_end - chunk_base) && g < 64u / R;
+            const uint32_t lam = sp.tail_first + j; /* < S by construction */
+            const double *table = SPDS_IN_LDS ? (const double *)lds : sc.spds;
+            double *px = film_pixels + pix_l * (uint64_t)(S + 1);
+            double *pa = film_avgs + pix_l * (uint64_t)S;
+            double *pv = film_vars + pix_l * (uint64_t)S;
+            double f_sum = act ? px[lam] : 0.0, f_avg = act ? pa[lam] : 0.0, f_var = act ? pv[lam] : 0.0;
+            for (uint32_t s = 0; s < sp.n_samples; s += 1)
+            {
+                const uint64_t slot = pix_l * sp.batch + s;
+                uint64_t h0 = 0, h1 = 0;
+                if (act)
+                {
+                    h0 = headers[slot * REC_HEADER_WORDS];
+                    h1 = headers[slot * REC_HEADER_WORDS + 1];
+                }
+                const uint32_t n_shaded = (uint32_t)(h0 & 0xFFFFu);
+                const uint32_t term = (uint32_t)(h0 >> 16) & 0xFFu;
+                const uint32_t term_spd = (uint32_t)(h0 >> 32) & 0xFFFFu;
+                const uint64_t *rp = records + slot * (uint64_t)sp.path_words;
+                double throughput = 1.0, dst = 0.0;
+                for (uint32_t v = 0; __any(v < n_shaded); v += 1)
+                {
+                    if (v >= n_shaded) continue;
+                    const uint64_t *vrec = rp + (uint64_t)v * vw;
+                    const uint64_t list = vrec[0], w1 = vrec[1];
+                    const double dir_pdf = word_as_double(vrec[4]);
+                    const double s_a_in = word_as_double(vrec[5]), s_spec = word_as_double(vrec[6]);
+                    const uint32_t num_bdsfs = (uint32_t)(w1 & 0xFFu);
+                    const uint32_t sflags = (uint32_t)(w1 >> 8) & 0xFFu;
+                    const uint32_t i_diffuse = (uint32_t)(w1 >> 16) & 0xFFFFu, i_glossy = (uint32_t)(w1 >> 32) & 0xFFFFu;
+                    double contribution = 0.0;
+                    if (sflags & FLAG_PLASTIC)
+                    {
+                        const double diffuse_pi = spd_at(table, S, i_diffuse, lam), glossy = spd_at(table, S, i_glossy, lam);
+                        for (uint32_t l = 0; l < sp.n_lights; l += 1)
+                        {
+                            const uint64_t *lrec = vrec + REC_VERTEX_WORDS + l * REC_LIGHT_WORDS;
+                            const uint64_t lw0 = lrec[0];
+                            if (!((uint32_t)(lw0 >> 16) & FLAG_VISIBLE)) continue;
+                            const double c = word_as_double(lrec[1]), a_in = word_as_double(lrec[2]), spec = word_as_double(lrec[3]);
+                            double reflectance = diffuse_pi * a_in + 0.0;
+                            reflectance = (glossy * spec) * a_in + reflectance;
+                            contribution = contribution + reflectance;
+                            contribution = contribution * spd_at(table, S, (uint32_t)(lw0 & 0xFFFFu), lam);
+                            contribution = contribution * c;
+                        }
+                        dst = dst + throughput * contribution;
+                        double reflectance = diffuse_pi * s_a_in + 0.0;
+                        reflectance = (glossy * s_spec) * s_a_in + reflectance;
+                        reflectance = reflectance * dir_pdf;
+                        throughput = throughput * reflectance;
+                    }
+                    else
+                    {
+                        const uint64_t w2 = vrec[2];
+                        const double on_dot = word_as_double(vrec[3]);
+                        const double diffuse_pi = spd_at(table, S, i_diffuse, lam), glossy = spd_at(table, S, i_glossy, lam);
+                        const double mirror = spd_at(table, S, (uint32_t)(w1 >> 48) & 0xFFFFu, lam);
+                        const double ir = spd_at(table, S, (uint32_t)(w2)&0xFFFFu, lam), tr = spd_at(table, S, (uint32_t)(w2 >> 16) & 0xFFFFu, lam);
+                        const double te = spd_at(table, S, (uint32_t)(w2 >> 32) & 0xFFFFu, lam);
+                        for (uint32_t l = 0; l < sp.n_lights; l += 1)
+                        {
+                            const uint64_t *lrec = vrec + REC_VERTEX_WORDS + l * REC_LIGHT_WORDS;
+                            const uint64_t lw0 = lrec[0];
+                            const uint32_t lflags = (uint32_t)(lw0 >> 16) & 0xFFu;
+                            if (!(lflags & FLAG_VISIBLE)) continue;
+                            double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse_pi, glossy, mirror, ir, tr, te, on_dot,
+                                                                    word_as_double(lrec[2]), word_as_double(lrec[3]), word_as_double(lrec[4]),
+                                                                    word_as_double(lrec[5]), lflags);
+                            contribution = contribution + reflectance;
+                            contribution = contribution * spd_at(table, S, (uint32_t)(lw0 & 0xFFFFu), lam);
+                            contribution = contribution * word_as_double(lrec[1]);
+                        }
+                        dst = dst + throughput * contribution;
+                        double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse_pi, glossy, mirror, ir, tr, te, on_dot, s_a_in, s_spec,
+                                                                word_as_double(vrec[7]), word_as_double(vrec[8]), sflags);
+                        reflectance = reflectance * dir_pdf;
+                        throughput = throughput * reflectance;
+                    }
+                }
+                if (term == 1) dst = dst + throughput * spd_at(table, S, term_spd, lam);
+                const double contribution = dst * word_as_double(h1);
+                const double denom = (double)(sp.first_sample + s + 1);
+                f_sum = f_sum + contribution;
+                double t0 = contribution - f_avg;
+                double t1 = t0;
+                t0 = t0 / denom;
+                f_avg = f_avg + t0;
+                t0 = contribution - f_avg;
+                t0 = t1 * t0;
+                f_var = f_var + t0;
+            }
+            if (act)
+            {
+                px[lam] = f_sum;
+                pa[lam] = f_avg;
+                pv[lam] = f_var;
+            }
+        }
     }
 }
 

@@ -61,6 +61,7 @@ struct drt_context
     bool   scene_in_lds = true, spds_in_lds = true, use_bvh = false;
     size_t trace_lds = 0, shade_lds = 0;
     int    trace_grid_cap = 0, shade_grid_cap = 0;
+    uint32_t shade_sets = 1, tail_first = 0, tail_count = 0;
     uint64_t n_pix = 0;
 
     std::vector<hipEvent_t> ev; /* triples: trace start, trace end / shade start, shade end */
@@ -391,9 +392,25 @@ static int launch_shade_sets(drt_context *ctx, uint32_t grid, const ShadeParams 
     return 0;
 }
 
+/* How the S wavelengths map to lanes: n full 64-lane sets, plus (when the remainder is small) a packed tail pass */
+static void shade_sets(uint32_t S, uint32_t *n_sets, uint32_t *tail_first, uint32_t *tail_count)
+{
+    uint32_t full = S / 64, rem = S % 64;
+    *tail_first = 0;
+    *tail_count = 0;
+    if (S <= 64 || rem == 0) *n_sets = (S + 63) / 64;
+    else if (rem <= 16 && !getenv("DRT_NO_TAIL_PASS"))
+    {
+        *n_sets = full;
+        *tail_first = 64 * full;
+        *tail_count = rem;
+    }
+    else *n_sets = full + 1;
+}
+
 static int launch_shade(drt_context *ctx, uint32_t grid, const ShadeParams &sp)
 {
-    switch ((ctx->dsc.S + 63) / 64)
+    switch (ctx->shade_sets)
     {
         case 1: return launch_shade_sets<1>(ctx, grid, sp);
         case 2: return launch_shade_sets<2>(ctx, grid, sp);
@@ -496,7 +513,8 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     /* shade kernel LDS: SPD tables + two record buffers per wave */
     ctx->shade_lds = ctx->spds_in_lds ? (size_t)ctx->dsc.n_spd * S * 8 : 0;
     int s_per_cu = 0;
-    switch ((S + 63) / 64)
+    shade_sets(S, &ctx->shade_sets, &ctx->tail_first, &ctx->tail_count);
+    switch (ctx->shade_sets)
     {
         case 1: rc = shade_occupancy<1>(ctx, &s_per_cu); break;
         case 2: rc = shade_occupancy<2>(ctx, &s_per_cu); break;
@@ -677,7 +695,11 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
         sp.path_words = ctx->path_words;
         sp.n_lights = ctx->dsc.n_lights;
         sp.batch = ctx->batch_spp;
-        uint32_t sgrid = (uint32_t)std::min<uint64_t>((ctx->n_pix + SHADE_WAVES - 1) / SHADE_WAVES, (uint64_t)ctx->shade_grid_cap);
+        sp.tail_first = ctx->tail_first;
+        sp.tail_count = ctx->tail_count;
+        sp.chunk = ctx->tail_count ? 64u / ctx->tail_count : SHADE_PIXEL_CHUNK;
+        uint64_t chunks = (ctx->n_pix + sp.chunk - 1) / sp.chunk;
+        uint32_t sgrid = (uint32_t)std::min<uint64_t>((chunks + SHADE_WAVES - 1) / SHADE_WAVES, (uint64_t)ctx->shade_grid_cap);
         rc = launch_shade(ctx, sgrid, sp);
         if (rc) return rc;
         HIP_TRY(hipGetLastError());
