@@ -922,7 +922,8 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
  * registers. The film is read and written once per batch. Waves are persistent (SPD tables staged
  * into LDS once) and draw chunks of pixels from a global counter, because pixel cost varies.
  */
-#define SHADE_PREFETCH_REGS 4 /* 64-word registers per path: 256 record words are prefetched, deeper paths fall back */
+#define SHADE_PREFETCH_REGS 2 /* 64-word registers per path: 128 record words are prefetched, deeper paths fall back */
+#define SHADE_PREFETCH_DEPTH 3 /* samples whose record loads are in flight ahead of the one being replayed */
 #define SHADE_PIXEL_CHUNK 16 /* default pixels per work chunk */
 
 template <int NSETS, bool SPDS_IN_LDS>
@@ -988,11 +989,16 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
             h1 = h[1];
         }
         const uint64_t *rbase = records + pix * (uint64_t)sp.batch * sp.path_words;
-        uint64_t nxt[SHADE_PREFETCH_REGS];
-        {
-            const uint32_t nw = (uint32_t)(readlane64(h0, 0) & 0xFFFFu) * vw;
+        /* ring of prefetched records: ring[0] = the sample being replayed, ring[d] = d samples ahead. Memory
+         * latency (~2 us) is several samples of replay, so the loads run SHADE_PREFETCH_DEPTH samples ahead. */
+        uint64_t ring[SHADE_PREFETCH_DEPTH + 1][SHADE_PREFETCH_REGS];
 #pragma unroll
-            for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) nxt[k] = (64u * k + lane < nw) ? rbase[64u * k + lane] : 0;
+        for (int d = 0; d < SHADE_PREFETCH_DEPTH; d += 1)
+        {
+            const uint32_t nw = ((uint32_t)d < sp.n_samples) ? (uint32_t)(readlane64(h0, d) & 0xFFFFu) * vw : 0u;
+            const uint64_t *p = rbase + (uint64_t)d * sp.path_words;
+#pragma unroll
+            for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) ring[d + 1][k] = (64u * k + lane < nw) ? p[64u * k + lane] : 0;
         }
         for (uint32_t s = 0; s < sp.n_samples; s += 1)
         {
@@ -1002,16 +1008,19 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
             const uint32_t term = (uint32_t)(hs >> 16) & 0xFFu;
             const uint32_t term_spd = (uint32_t)(hs >> 32) & 0xFFFFu;
             const uint64_t *p_s = rbase + (uint64_t)s * sp.path_words;
-            uint64_t cur[SHADE_PREFETCH_REGS];
+            /* rotate the ring, then start the load for the sample SHADE_PREFETCH_DEPTH ahead */
 #pragma unroll
-            for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) cur[k] = nxt[k];
-            if (s + 1 < sp.n_samples)
+            for (int d = 0; d < SHADE_PREFETCH_DEPTH; d += 1)
+#pragma unroll
+                for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) ring[d][k] = ring[d + 1][k];
             {
-                const uint32_t nw = (uint32_t)(readlane64(h0, s + 1) & 0xFFFFu) * vw;
-                const uint64_t *p = p_s + sp.path_words;
+                const uint32_t sa = s + SHADE_PREFETCH_DEPTH;
+                const uint32_t nw = (sa < sp.n_samples) ? (uint32_t)(readlane64(h0, sa) & 0xFFFFu) * vw : 0u;
+                const uint64_t *p = rbase + (uint64_t)sa * sp.path_words;
 #pragma unroll
-                for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) nxt[k] = (64u * k + lane < nw) ? p[64u * k + lane] : 0;
+                for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) ring[SHADE_PREFETCH_DEPTH][k] = (64u * k + lane < nw) ? p[64u * k + lane] : 0;
             }
+            const uint64_t *cur = ring[0];
 
             double throughput[NSETS], dst[NSETS];
 #pragma unroll
@@ -1029,7 +1038,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
                 {
                     const uint32_t sel = v / vpr;
                     lane0 = (v - sel * vpr) * vw;
-                    src = sel == 0 ? cur[0] : sel == 1 ? cur[1] : sel == 2 ? cur[2] : cur[3];
+                    src = sel == 0 ? cur[0] : cur[1];
                 }
                 else
                 {

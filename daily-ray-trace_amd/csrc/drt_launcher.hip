@@ -475,7 +475,7 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     uint32_t batch = params->batch_spp;
     if (batch == 0)
     {
-        uint64_t target_paths = 16ull << 20;
+        uint64_t target_paths = 32ull << 20;
         batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, target_paths / std::max<uint64_t>(ctx->n_pix, 1)));
     }
     batch = std::min<uint32_t>(batch, 64); /* one header lane per sample in the shade kernel */
