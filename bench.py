@@ -216,7 +216,8 @@ def main():
                          "kernel_ms_per_step": {"trace": round(trace_ms / args.steps, 3), "shade": round(shade_ms / args.steps, 3)},
                          "whole_path_GBs": round(model["path"] * (total_paths / elapsed) / 1e9, 1),
                          "v_int": round(v_int, 4), "v_shade": round(v_shade, 4),
-                         "note": "achieved = SURVEY 8d algorithmic bytes of the dominant kernel / its HIP-event time on rank 0; "
+                         "note": "achieved = SURVEY 8d algorithmic bytes of the dominant kernel / its HIP-event time on rank 0 (the model "
+                                 "assumes path state streamed through HBM; this design keeps it in registers, so frac can exceed 1: see traffic); "
                                  "traffic = HBM bytes per launch of that kernel from the committed rocprofv3 PMC profile (profiles/traffic.json), when it matches"},
         }
         if world > 1:
