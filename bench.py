@@ -122,8 +122,8 @@ def main():
                                device=local_rank, batch_spp=args.batch)
     dev = torch.device("cuda", local_rank)
     n_tile = tile_h * W
-    film = [torch.zeros((n_tile, S + 1), dtype=torch.float64, device=dev), torch.zeros((n_tile, S), dtype=torch.float64, device=dev),
-            torch.zeros((n_tile, S), dtype=torch.float64, device=dev)]
+    fg = drt_dist.FilmGather(H, W, S, rank, world, dev)  # the rank's film: one contiguous buffer, three regions
+    film = [fg.region(0), fg.region(1), fg.region(2)]
     r = pydrt.Renderer(bundle, params)
     r.bind_film(film[0].data_ptr(), film[1].data_ptr(), film[2].data_ptr())
     stream = torch.cuda.current_stream()
@@ -140,15 +140,12 @@ def main():
     gather_ms = [0.0]
 
     def step():
-        for t in film:
-            t.zero_()
+        fg.zero_()
         r.render(0, args.spp)
         if world > 1:
             t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
             t0.record()
-            for t, c in zip(film, (S + 1, S, S)):
-                tile = t.reshape(tile_h, W, c)
-                drt_dist.gather_tiles(tile.cpu() if staging else tile, H, W, rank, world)
+            fg.gather(staging=staging)  # the single gather that reassembles the frame on rank 0
             t1.record()
             torch.cuda.synchronize()
             gather_ms[0] += t0.elapsed_time(t1)

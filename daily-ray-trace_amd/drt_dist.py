@@ -55,3 +55,49 @@ def render_distributed(render_tile_fn, height, width, rank, world, channels, dst
         img = gather_tiles(t.reshape(tile_h, width, c), height, width, rank, world, dst=dst, group=group)
         out.append(img)
     return out if rank == dst else None
+
+
+class FilmGather:
+    """The film of a rank as ONE contiguous buffer (sum+filter | mean | variance regions), so reassembling the frame
+    is a single gather with a receive buffer allocated once. Rows are row-cyclic over the ranks."""
+
+    def __init__(self, height, width, S, rank, world, device, dst=0):
+        self.height, self.width, self.S, self.rank, self.world, self.dst = height, width, S, rank, world, dst
+        self.rows = rank_rows(height, rank, world)[1]
+        self.rows_max = max_tile_rows(height, world)
+        self.channels = (S + 1, S, S)
+        n_max = self.rows_max * width
+        self.offsets = [0, n_max * (S + 1), n_max * (2 * S + 1)]
+        self.flat = torch.zeros(n_max * (3 * S + 1), dtype=torch.float64, device=device)
+        self.recv = torch.empty((world, self.flat.numel()), dtype=torch.float64, device=device) if (rank == dst and world > 1) else None
+        self.image = [torch.empty((height, width, c), dtype=torch.float64, device=device) for c in self.channels] if rank == dst else None
+
+    def region(self, i):
+        """Film buffer i (0 sum+filter, 1 mean, 2 variance) of this rank's tile: [rows*width, C_i], a view into flat."""
+        n = self.rows * self.width
+        return self.flat[self.offsets[i]: self.offsets[i] + n * self.channels[i]].view(n, self.channels[i])
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def gather(self, group=None, staging=False):
+        """One collective; returns the three full-frame buffers on dst, None elsewhere."""
+        if self.world == 1:
+            for i in range(3):
+                self.image[i].copy_(self.region(i).view(self.rows, self.width, self.channels[i]))
+            return self.image
+        send = self.flat.cpu() if staging else self.flat
+        if self.rank == self.dst:
+            recv = self.recv.cpu() if staging else self.recv
+            dist.gather(send, gather_list=[recv[r] for r in range(self.world)], dst=self.dst, group=group)
+            if staging:
+                self.recv.copy_(recv)
+            for r in range(self.world):
+                rows = rank_rows(self.height, r, self.world)[1]
+                n = rows * self.width
+                for i, c in enumerate(self.channels):
+                    part = self.recv[r, self.offsets[i]: self.offsets[i] + n * c].view(rows, self.width, c)
+                    self.image[i][r::self.world] = part
+            return self.image
+        dist.gather(send, gather_list=None, dst=self.dst, group=group)
+        return None

@@ -39,6 +39,17 @@ def _worker(rank, world, port, height, width, out_path):
         return [torch.from_numpy(px), torch.from_numpy(av), torch.from_numpy(va)]
 
     full = drt_dist.render_distributed(render_tile, height, width, rank, world, channels=(S + 1, S, S))
+    # the single-collective form bench.py uses: one contiguous film buffer per rank, one gather
+    fg = drt_dist.FilmGather(height, width, S, rank, world, torch.device("cpu"))
+    y0, tile_h, stride = drt_dist.rank_rows(height, rank, world)
+    for i, t in enumerate(render_tile(y0, tile_h, stride)):
+        fg.region(i).copy_(t)
+    flat_full = fg.gather()
+    if rank == 0:
+        for a, b in zip(full, flat_full):
+            assert torch.equal(a, b)
+    else:
+        assert flat_full is None
     dist.barrier()
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the max-over-ranks timing reduction bench.py uses
