@@ -753,6 +753,18 @@ extern "C" int drt_read_film(drt_context *ctx, double *pixels, double *avgs, dou
     return 0;
 }
 
+extern "C" int drt_write_film(drt_context *ctx, const double *pixels, const double *avgs, const double *vars)
+{
+    if (!ctx) return fail(-1, "null context");
+    int rc = drt_synchronize(ctx);
+    if (rc) return rc;
+    const size_t S = ctx->dsc.S;
+    if (pixels) HIP_TRY(hipMemcpy(ctx->d_pixels, pixels, (size_t)ctx->n_pix * (S + 1) * 8, hipMemcpyHostToDevice));
+    if (avgs) HIP_TRY(hipMemcpy(ctx->d_avgs, avgs, (size_t)ctx->n_pix * S * 8, hipMemcpyHostToDevice));
+    if (vars) HIP_TRY(hipMemcpy(ctx->d_vars, vars, (size_t)ctx->n_pix * S * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+
 extern "C" int drt_read_xyz(drt_context *ctx, double *xyz)
 {
     if (!ctx || !xyz) return fail(-1, "null argument");
@@ -808,18 +820,10 @@ extern "C" int drt_render_tile(const drt_scene *scene, const drt_camera *camera,
     drt_context *ctx = drt_create(scene, camera, params);
     if (!ctx) return -1;
     int rc = 0;
-    const size_t S = ctx->dsc.S;
     do
     {
         /* accumulate INTO the caller's buffers: start from their contents */
-        hipError_t e;
-        if ((e = hipMemcpy(ctx->d_pixels, dst_pixels, (size_t)ctx->n_pix * (S + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess ||
-            (e = hipMemcpy(ctx->d_avgs, dst_avgs, (size_t)ctx->n_pix * S * 8, hipMemcpyHostToDevice)) != hipSuccess ||
-            (e = hipMemcpy(ctx->d_vars, dst_vars, (size_t)ctx->n_pix * S * 8, hipMemcpyHostToDevice)) != hipSuccess)
-        {
-            rc = fail(-100 - (int)e, "film upload: %s", hipGetErrorString(e));
-            break;
-        }
+        if ((rc = drt_write_film(ctx, dst_pixels, dst_avgs, dst_vars))) break;
         if ((rc = drt_render(ctx, params->first_sample, params->spp))) break;
         if ((rc = drt_read_film(ctx, dst_pixels, dst_avgs, dst_vars))) break;
         if (stats && (rc = drt_get_stats(ctx, stats))) break;

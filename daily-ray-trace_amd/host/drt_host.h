@@ -78,13 +78,15 @@ typedef struct
 } spd_file_header;
 
 /* Host extras that the reference has no field for (device choice, RNG seed, batch size);
- * read from the environment by render_image(): DRT_DEVICE, DRT_SEED, DRT_BATCH_SPP. */
+ * read from the environment by render_image(): DRT_DEVICE, DRT_SEED, DRT_BATCH_SPP, DRT_CHECKPOINT_SPP, DRT_RESUME. */
 typedef struct
 {
     int32_t  device;
     uint64_t seed;
     uint32_t batch_spp;
     uint32_t quiet;
+    uint32_t checkpoint_spp; /* rewrite the .spd files every this many samples (0: only at the end) */
+    uint32_t resume;         /* continue from the .spd files of an earlier (checkpointed) run */
 } drt_host_options;
 
 /* Fills *config from the text of a config.cfg. Unknown keys are fatal (exit(-1)), like the reference.

@@ -1,9 +1,10 @@
 /*
  * drt_render.c -- render_image() for the POSIX + HIP host (replaces src/daily_ray_trace.c:635-777).
  *
- * Same inputs (config_arguments) and outputs (three .spd files) as the reference. The
- * `for sample / for y / for x` loop (src/daily_ray_trace.c:710-745) is ONE call into the
- * C-ABI launcher (drt_render_tile, include/drt_hip.h); everything around it stays plain C.
+ * Same inputs (config_arguments) and outputs (three .spd files, then the three BMPs of the reference's
+ * main()). The `for sample / for y / for x` loop (src/daily_ray_trace.c:710-745) is the C-ABI launcher
+ * (include/drt_hip.h: drt_create / drt_render / drt_read_film, the session form of drt_render_tile, so the
+ * film can stay on the device between checkpoints); everything around it stays plain C.
  * There is no CPU fallback: if the launcher fails, render_image reports it and exits.
  */
 #include "drt_host.h"
@@ -18,6 +19,31 @@ static f64 now_ms(void)
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (f64)ts.tv_sec * 1000.0 + (f64)ts.tv_nsec * 1e-6;
+}
+
+/* The three .spd outputs (src/daily_ray_trace.c:758-770): sum+filter, mean, and the variance max-normalised per
+ * pixel (:766-769, on a copy so the accumulators stay usable); optionally the raw variance for a later resume. */
+static int write_outputs(const config_arguments *config, const drt_scene *scene, u32 width, u32 height, const f64 *dst_pixels,
+                         const f64 *dst_avgs, const f64 *dst_vars, const char *raw_var_path)
+{
+    u32 S = scene->num_wavelengths;
+    u64 num_pixels = (u64)width * height;
+    f64 *norm = (f64 *)malloc(num_pixels * S * sizeof(f64));
+    if (!norm) return -1;
+    for (u64 px = 0; px < num_pixels; px += 1)
+    {
+        const f64 *v = dst_vars + px * S;
+        f64 *o = norm + px * S;
+        f64 highest = 0.0;
+        for (u32 i = 0; i < S; i += 1) if (v[i] > highest) highest = v[i];
+        for (u32 i = 0; i < S; i += 1) o[i] = v[i] / highest;
+    }
+    int w0 = drt_host_write_spd(config->output_spd, width, height, S, 1, scene->min_wavelength, scene->wavelength_interval, dst_pixels);
+    int w1 = drt_host_write_spd(config->variance_spd, width, height, S, 0, scene->min_wavelength, scene->wavelength_interval, norm);
+    int w2 = drt_host_write_spd(config->average_spd, width, height, S, 0, scene->min_wavelength, scene->wavelength_interval, dst_avgs);
+    int w3 = raw_var_path ? drt_host_write_spd(raw_var_path, width, height, S, 0, scene->min_wavelength, scene->wavelength_interval, dst_vars) : 0;
+    free(norm);
+    return (w0 || w1 || w2 || w3) ? -1 : 0;
 }
 
 int render_image_ex(config_arguments *config, const drt_host_options *opt, drt_stats *stats_out)
@@ -71,14 +97,60 @@ int render_image_ex(config_arguments *config, const drt_host_options *opt, drt_s
     p.device = opt ? opt->device : 0;
     p.batch_spp = opt ? opt->batch_spp : 0;
 
+    /*
+     * Progressive accumulation (the reference only sketches it, src/daily_ray_trace.c:620-633): the
+     * film lives on the device for the whole render; every `checkpoint_spp` samples the three .spd files are
+     * rewritten, plus the un-normalised variance (<variance_spd>.raw) that a resumed run needs. A resumed run
+     * (opt->resume) reloads those files, takes the number of samples done from the filter sum, and continues --
+     * bit-identical to an uninterrupted run, because sample k always uses the same per-path seeds.
+     */
     drt_stats stats;
     memset(&stats, 0, sizeof(stats));
+    u32 done = 0;
+    char raw_var_path[96];
+    snprintf(raw_var_path, sizeof(raw_var_path), "%s.raw", config->variance_spd);
+    if (opt && opt->resume)
+    {
+        spd_file_header h0, h1, h2;
+        f64 *p0 = NULL, *p1 = NULL, *p2 = NULL;
+        if (drt_host_read_spd(config->output_spd, &h0, &p0) == 0 && drt_host_read_spd(config->average_spd, &h1, &p1) == 0 &&
+            drt_host_read_spd(raw_var_path, &h2, &p2) == 0 && h0.width_in_pixels == width && h0.height_in_pixels == height &&
+            h0.number_of_wavelengths == S && h0.has_filter_values && h1.number_of_wavelengths == S && h2.number_of_wavelengths == S)
+        {
+            memcpy(dst_pixels, p0, num_pixels * (S + 1) * sizeof(f64));
+            memcpy(dst_avgs, p1, num_pixels * S * sizeof(f64));
+            memcpy(dst_vars, p2, num_pixels * S * sizeof(f64));
+            done = (u32)dst_pixels[S]; /* filter sum of pixel 0 = samples accumulated so far (filter value is 1) */
+            if (!(opt && opt->quiet)) printf("Resuming after %u samples\n", done);
+        }
+        else fprintf(stderr, "render_image: nothing to resume from, starting at sample 0\n");
+        free(p0); free(p1); free(p2);
+    }
     f64 t0 = now_ms();
-    int rc = drt_render_tile(scene, drt_host_camera_data(hs), &p, dst_pixels, dst_avgs, dst_vars, &stats);
+    int rc = 0;
+    drt_context *ctx = drt_create(scene, drt_host_camera_data(hs), &p);
+    if (!ctx) rc = -1;
+    if (!rc && done) rc = drt_write_film(ctx, dst_pixels, dst_avgs, dst_vars);
+    u32 step = (opt && opt->checkpoint_spp) ? opt->checkpoint_spp : p.spp;
+    while (!rc && done < p.spp)
+    {
+        u32 n = (p.spp - done < step) ? p.spp - done : step;
+        if ((rc = drt_render(ctx, done, n))) break;
+        done += n;
+        if (done < p.spp) /* a checkpoint: the final write below uses the same code */
+        {
+            if ((rc = drt_read_film(ctx, dst_pixels, dst_avgs, dst_vars))) break;
+            if (write_outputs(config, scene, width, height, dst_pixels, dst_avgs, dst_vars, raw_var_path)) fprintf(stderr, "render_image: checkpoint write failed\n");
+            if (!(opt && opt->quiet)) printf("Checkpoint at %u / %u samples\n", done, p.spp);
+        }
+    }
+    if (!rc) rc = drt_read_film(ctx, dst_pixels, dst_avgs, dst_vars);
+    if (!rc) rc = drt_get_stats(ctx, &stats);
+    drt_destroy(ctx);
     f64 t1 = now_ms();
     if (rc != 0)
     {
-        fprintf(stderr, "render_image: drt_render_tile failed (%d): %s\n", rc, drt_last_error());
+        fprintf(stderr, "render_image: the HIP launcher failed (%d): %s\n", rc, drt_last_error());
         return rc;
     }
     if (!(opt && opt->quiet))
@@ -90,18 +162,8 @@ int render_image_ex(config_arguments *config, const drt_host_options *opt, drt_s
                (f64)stats.shaded_vertices / (f64)stats.paths, (f64)stats.paths / (stats.total_ms * 1e3));
     }
 
-    /* variance is max-normalised per pixel before writing (src/daily_ray_trace.c:766-769) */
-    for (u64 px = 0; px < num_pixels; px += 1)
-    {
-        f64 *v = dst_vars + px * S;
-        f64 highest = 0.0;
-        for (u32 i = 0; i < S; i += 1) if (v[i] > highest) highest = v[i];
-        for (u32 i = 0; i < S; i += 1) v[i] /= highest;
-    }
-    int w0 = drt_host_write_spd(config->output_spd, width, height, S, 1, scene->min_wavelength, scene->wavelength_interval, dst_pixels);
-    int w1 = drt_host_write_spd(config->variance_spd, width, height, S, 0, scene->min_wavelength, scene->wavelength_interval, dst_vars);
-    int w2 = drt_host_write_spd(config->average_spd, width, height, S, 0, scene->min_wavelength, scene->wavelength_interval, dst_avgs);
-    if (w0 || w1 || w2) fprintf(stderr, "render_image: could not write one of the .spd outputs\n");
+    int wrc = write_outputs(config, scene, width, height, dst_pixels, dst_avgs, dst_vars, (opt && opt->checkpoint_spp) ? raw_var_path : NULL);
+    int w0 = wrc, w1 = 0, w2 = 0;
     /* post-process like the reference's main(): each .spd -> linear RGB -> BMP (src/win32_main.c:150-152) */
     if (!(w0 || w1 || w2) && config->output_bmp[0])
     {
@@ -128,5 +190,7 @@ void render_image(config_arguments *config)
     if ((e = getenv("DRT_DEVICE"))) opt.device = atoi(e);
     if ((e = getenv("DRT_SEED"))) opt.seed = strtoull(e, NULL, 0);
     if ((e = getenv("DRT_BATCH_SPP"))) opt.batch_spp = (u32)atoi(e);
+    if ((e = getenv("DRT_CHECKPOINT_SPP"))) opt.checkpoint_spp = (u32)atoi(e);
+    if ((e = getenv("DRT_RESUME"))) opt.resume = (u32)atoi(e);
     if (render_image_ex(config, &opt, NULL) != 0) exit(-1);
 }

@@ -273,6 +273,7 @@ def hip_lib():
         L.drt_film_device_ptrs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         L.drt_read_film.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.drt_read_xyz.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.drt_write_film.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.drt_read_hit_indices.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_uint64]
         L.drt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.drt_batch_spp.restype = C.c_uint32
@@ -286,7 +287,7 @@ def hip_lib():
 
 
 HIP_SYMBOLS = ["drt_last_error", "drt_device_count", "drt_create", "drt_destroy", "drt_bind_film", "drt_set_stream",
-               "drt_render", "drt_synchronize", "drt_reset_film", "drt_film_device_ptrs", "drt_read_film",
+               "drt_render", "drt_synchronize", "drt_reset_film", "drt_film_device_ptrs", "drt_read_film", "drt_write_film",
                "drt_read_xyz", "drt_read_hit_indices", "drt_get_stats", "drt_batch_spp", "drt_render_tile", "drt_selftest_arith"]
 
 
@@ -347,6 +348,10 @@ class Renderer:
         va = np.empty((self.n_pixels, self.S), dtype=np.float64)
         _check(self.L.drt_read_film(self.ctx, _ptr(px, C.c_double), _ptr(av, C.c_double), _ptr(va, C.c_double)), "drt_read_film")
         return px, av, va
+
+    def write_film(self, px, av, va):
+        px, av, va = (np.ascontiguousarray(a, dtype=np.float64) for a in (px, av, va))
+        _check(self.L.drt_write_film(self.ctx, _ptr(px, C.c_double), _ptr(av, C.c_double), _ptr(va, C.c_double)), "drt_write_film")
 
     def read_xyz(self):
         xyz = np.empty((self.n_pixels, 3), dtype=np.float64)

@@ -206,6 +206,8 @@ int drt_reset_film(drt_context *ctx);
 int drt_film_device_ptrs(drt_context *ctx, void **d_pixels, void **d_avgs, void **d_vars);
 /* Copy the film to host buffers (any may be NULL). Synchronises. */
 int drt_read_film(drt_context *ctx, double *pixels, double *avgs, double *vars);
+/* Replace the film with host data (any pointer may be NULL to leave that buffer as is): resuming from a checkpoint. */
+int drt_write_film(drt_context *ctx, const double *pixels, const double *avgs, const double *vars);
 /* Per-pixel XYZ of sum/filter (spectrum_to_xyz on the device), [tile_h*tile_w][3]. Synchronises. */
 int drt_read_xyz(drt_context *ctx, double *xyz);
 /* Closest-hit surface indices of the LAST rendered sample batch: [n][max_depth] int32 per path

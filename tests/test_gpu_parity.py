@@ -218,3 +218,44 @@ def test_torch_owned_film_and_stream():
     opx, oav, ova, _, _ = O.oracle_render_tile(bundle, params, math_mode=O.MATH_DEVICE)
     assert cases.rel_err(t_px.cpu().numpy(), opx) <= FILM_TOL and cases.rel_err(t_va.cpu().numpy(), ova) <= FILM_TOL
     r.close()
+
+
+def test_drt_render_program_checkpoint_and_resume(tmp_path):
+    """The POSIX + HIP program end to end (N3): a run checkpointed every 2 samples and cut short after 4, then
+    resumed to 6, writes the same three .spd files, bit for bit, as an uninterrupted 6-sample run."""
+    import shutil
+    import subprocess
+    exe = os.path.join(cases.REPO, "daily-ray-trace_amd", "drt_render")
+    assert os.path.exists(exe)
+
+    def run(workdir, spp, env_extra):
+        os.makedirs(os.path.join(workdir, "output"), exist_ok=True)
+        for d in ("scenes", "spectra"):
+            if not os.path.exists(os.path.join(workdir, d)):
+                os.symlink(os.path.join(cases.REPO, d), os.path.join(workdir, d))
+        cfg = open(os.path.join(cases.REPO, "config.cfg")).read()
+        cfg = cfg.replace("num_pixel_samples 4", "num_pixel_samples %d" % spp).replace("output_width      800", "output_width      96")
+        cfg = cfg.replace("output_height     600", "output_height     64").replace("max_cast_depth    4", "max_cast_depth    6")
+        open(os.path.join(workdir, "config.cfg"), "w").write(cfg)
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([exe], cwd=workdir, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+        return r.stdout
+
+    a = str(tmp_path / "a"); b = str(tmp_path / "b")
+    os.makedirs(a); os.makedirs(b)
+    run(a, 6, {})
+    out1 = run(b, 4, {"DRT_CHECKPOINT_SPP": "2"})
+    assert "Checkpoint at 2 / 4 samples" in out1
+    out2 = run(b, 6, {"DRT_CHECKPOINT_SPP": "2", "DRT_RESUME": "1"})
+    assert "Resuming after 4 samples" in out2
+    for f in ("output.spd", "average.spd", "variance.spd", "output.bmp"):
+        assert open(os.path.join(a, "output", f), "rb").read() == open(os.path.join(b, "output", f), "rb").read(), f
+    # and the film agrees with the oracle
+    hdr = np.fromfile(os.path.join(a, "output", "output.spd"), dtype=np.uint32, count=5)
+    assert list(hdr[1:5]) == [96, 64, 69, 1]
+    px = np.fromfile(os.path.join(a, "output", "output.spd"), dtype=np.float64, offset=40).reshape(-1, 70)
+    bundle = pydrt.load_scene(cases.scene_path("cornell_plane_light.scn"), 96, 64)
+    p = pydrt.make_params(96, 64, spp=6, max_depth=6, seed=1)
+    opx, _, _, _, _ = O.oracle_render_tile(bundle, p, math_mode=O.MATH_DEVICE, num_threads=4)
+    assert cases.rel_err(px, opx) <= FILM_TOL
