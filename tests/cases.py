@@ -28,16 +28,22 @@ RENDER_CASES = {
     "lens": ("test_lens.scn", 24, 24, 3, 4, 2, pydrt.FILM_SAMPLE_RANDOM),  # thin-lens camera
     "many_lights": ("test_many_lights.scn", 24, 24, 2, 5, 4, pydrt.FILM_SAMPLE_RANDOM),  # 12 lights: vertex records wider than a 64-word register
     "deep_paths": ("cornell_large_box.scn", 16, 16, 2, 40, 6, pydrt.FILM_SAMPLE_RANDOM),  # more vertices than the shade kernel prefetches
+    # other wavelength grids: S = 35 (one partial set), 86 (two sets, no tail pass), 137 (two sets + a 9-wide tail);
+    # with the 4 nm grid trans_wl = 630 falls between two samples, so value_at_wl really interpolates
+    "grid_10nm": ("cornell_plane_light.scn", 20, 20, 3, 6, 8, pydrt.FILM_SAMPLE_RANDOM, (380.0, 720.0, 10.0)),
+    "grid_4nm": ("cornell_plane_light.scn", 20, 20, 3, 6, 8, pydrt.FILM_SAMPLE_RANDOM, (380.0, 720.0, 4.0)),
+    "grid_2p5nm": ("cornell_plane_light.scn", 20, 20, 3, 6, 8, pydrt.FILM_SAMPLE_RANDOM, (380.0, 720.0, 2.5)),
     "spheres_1500": ("@spheres:1500", 32, 32, 2, 6, 9, pydrt.FILM_SAMPLE_RANDOM),  # config 5 generator, reduced
 }
 
 
 def load_case(name):
-    scene, w, h, spp, depth, seed, scheme = RENDER_CASES[name]
+    scene, w, h, spp, depth, seed, scheme = RENDER_CASES[name][:7]
+    grid = RENDER_CASES[name][7] if len(RENDER_CASES[name]) > 7 else (380.0, 720.0, 5.0)
     if scene.startswith("@spheres:"):
         bundle = pydrt.synthetic_sphere_scene(int(scene.split(":")[1]), w, h)
     else:
-        bundle = pydrt.load_scene(scene_path(scene), w, h)
+        bundle = pydrt.load_scene(scene_path(scene), w, h, min_wl=grid[0], max_wl=grid[1], wl_interval=grid[2])
     params = pydrt.make_params(w, h, spp=spp, max_depth=depth, seed=seed, pixel_scheme=scheme)
     return bundle, params
 

@@ -259,3 +259,46 @@ def test_drt_render_program_checkpoint_and_resume(tmp_path):
     p = pydrt.make_params(96, 64, spp=6, max_depth=6, seed=1)
     opx, _, _, _, _ = O.oracle_render_tile(bundle, p, math_mode=O.MATH_DEVICE, num_threads=4)
     assert cases.rel_err(px, opx) <= FILM_TOL
+
+
+def test_edge_cases_empty_scene_and_single_pixel():
+    """No surfaces at all (every path escapes at depth 0), a 1x1 image, one sample, depth 1, an odd-sized tile."""
+    empty = """Camera
+position 0.0, 0.0, 8.0
+target   0.0, 0.0, 0.0
+fov 90.0
+fdepth 6.0
+flength 0.3
+Material
+name vacuum
+refract constant 1.0
+base_material
+Material
+name escape
+escape_material
+"""
+    b = pydrt.load_scene_text(empty, 7, 5)
+    p = pydrt.make_params(7, 5, spp=3, max_depth=4, seed=2)
+    px, av, va, hits, xyz, st = hip_render(b, p)
+    assert (hits[:, 0] == -1).all() and (hits[:, 1:] == -2).all()
+    assert np.all(px[:, :b.S] == 0.0) and np.all(px[:, b.S] == 3.0) and np.all(av == 0.0) and np.all(va == 0.0)
+    assert st.closest_hit_scans == st.paths == 7 * 5 * 3 and st.shaded_vertices == 0
+    opx, oav, ova, ohits, ost = O.oracle_render_tile(b, p, want_hits=True, math_mode=O.MATH_DEVICE)
+    assert np.array_equal(px, opx) and np.array_equal(hits, ohits) and st.rng_draws == ost.rng_draws
+
+    b1 = pydrt.load_scene(cases.scene_path("cornell_plane_light.scn"), 1, 1)
+    for spp, depth in ((1, 1), (5, 3), (70, 2)):  # 70 samples: more than one batch of the 64-sample cap
+        p1 = pydrt.make_params(1, 1, spp=spp, max_depth=depth, seed=9)
+        px, av, va, hits, xyz, st = hip_render(b1, p1)
+        opx, oav, ova, ohits, ost = O.oracle_render_tile(b1, p1, want_hits=True, math_mode=O.MATH_DEVICE)
+        assert np.array_equal(hits, ohits)
+        assert cases.rel_err(px, opx) <= FILM_TOL and cases.rel_err(av, oav) <= FILM_TOL and cases.rel_err(va, ova) <= FILM_TOL
+        assert px[0, b1.S] == float(spp)
+
+    b2 = pydrt.load_scene(cases.scene_path("cornell_plane_light.scn"), 37, 23)
+    p2 = pydrt.make_params(37, 23, spp=2, max_depth=5, seed=4, x0=3, y0=1, tile_w=29, tile_h=7, row_stride=3)
+    px, av, va, hits, xyz, st = hip_render(b2, p2)
+    opx, oav, ova, ohits, ost = O.oracle_render_tile(b2, p2, want_hits=True, math_mode=O.MATH_DEVICE)
+    assert np.array_equal(hits, ohits) and cases.rel_err(px, opx) <= FILM_TOL and cases.rel_err(va, ova) <= FILM_TOL
+    bad = pydrt.make_params(37, 23, spp=1, max_depth=2, x0=10, tile_w=30)  # tile runs off the image
+    assert not pydrt.hip_lib().drt_create(C.byref(b2.scene), C.byref(b2.camera), C.byref(bad))
