@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--batch", type=int, default=0, help="samples per kernel pair (0 = library default)")
+    ap.add_argument("--gather-blocks", type=int, default=0, help="row blocks per rank (0 = 1 at N=1, 4 at N>1)")
+    ap.add_argument("--block-streams", type=int, default=1, help="HIP streams the row blocks are spread over (blocks on different streams overlap)")
+    ap.add_argument("--checksum", action="store_true", help="add an order-independent checksum of the assembled frame to the JSON line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: all ranks use GPU 0 (needs --backend gloo)")
@@ -117,17 +120,33 @@ def main():
     scene_file = os.path.join(REPO, "scenes", "cornell_plane_light.scn")
     bundle = pydrt.load_scene(scene_file, W, H)
     S = bundle.S
-    y0, tile_h, stride = drt_dist.rank_rows(H, rank, world)
-    params = pydrt.make_params(W, H, spp=args.spp, max_depth=args.depth, seed=1, y0=y0, tile_h=tile_h, row_stride=stride,
-                               device=local_rank, batch_spp=args.batch)
     dev = torch.device("cuda", local_rank)
-    n_tile = tile_h * W
-    fg = drt_dist.FilmGather(H, W, S, rank, world, dev)  # the rank's film: one contiguous buffer, three regions
-    film = [fg.region(0), fg.region(1), fg.region(2)]
-    r = pydrt.Renderer(bundle, params)
-    r.bind_film(film[0].data_ptr(), film[1].data_ptr(), film[2].data_ptr())
-    stream = torch.cuda.current_stream()
-    r.set_stream(stream.cuda_stream)
+    n_tile = drt_dist.rank_rows(H, rank, world)[1] * W
+    # The rank's rows (cyclic over the ranks) in row blocks: each block is one contiguous film buffer (three regions)
+    # with its own render context; block b's gather to rank 0 is in flight while block b+1 renders.
+    # Blocks of >= 128k pixels keep the kernels' last rounds short; at least 2 so a gather can hide.
+    n_blocks = args.gather_blocks if args.gather_blocks > 0 else (max(2, min(8, n_tile // (128 * 1024))) if world > 1 else 1)
+    blocks = drt_dist.film_blocks(H, W, S, rank, world, dev, n_blocks)
+    # One explicit (non-default) stream carries the film zero-fill, the kernels, the collectives' dependencies and the
+    # de-interleave copies. The default stream's handle is 0, which drt_set_stream() reads as "the context's own stream":
+    # the gather would then not wait for the render.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    block_streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(max(1, args.block_streams) - 1)]
+    renderers = []
+    for b, fb in enumerate(blocks):
+        by0, brows, bstride = fb.tile()
+        if brows == 0:
+            renderers.append(None)
+            continue
+        params = pydrt.make_params(W, H, spp=args.spp, max_depth=args.depth, seed=1, y0=by0, tile_h=brows, row_stride=bstride,
+                                   device=local_rank, batch_spp=args.batch)
+        r = pydrt.Renderer(bundle, params)
+        r.bind_film(fb.region(0).data_ptr(), fb.region(1).data_ptr(), fb.region(2).data_ptr())
+        r.set_stream(block_streams[b % len(block_streams)].cuda_stream)
+        renderers.append(r)
+    live = [r for r in renderers if r is not None]
 
     staging = args.backend != "nccl"  # gloo rehearsal: collectives on host copies
 
@@ -139,42 +158,69 @@ def main():
 
     gather_ms = [0.0]
 
+    side = torch.cuda.Stream(device=dev)  # rank 0 de-interleaves a gathered block here while the next block renders
+
+    def finish_on_side(fb):
+        with torch.cuda.stream(side):
+            fb.finish()
+
     def step():
-        fg.zero_()
-        r.render(0, args.spp)
+        for bs in block_streams[1:]:
+            bs.wait_stream(stream)
+        prev = None
+        for b, (fb, r) in enumerate(zip(blocks, renderers)):
+            with torch.cuda.stream(block_streams[b % len(block_streams)]):
+                fb.zero_()
+                if r is not None:
+                    r.render(0, args.spp)
+                if world > 1:
+                    fb.gather_async(staging=staging)
+            if world > 1:
+                if prev is not None:
+                    finish_on_side(prev)
+                prev = fb
+        for bs in block_streams[1:]:
+            stream.wait_stream(bs)
         if world > 1:
+            # what is left of the gathers once the last block has rendered = the part not hidden behind compute
             t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
             t0.record()
-            fg.gather(staging=staging)  # the single gather that reassembles the frame on rank 0
+            finish_on_side(prev)
+            stream.wait_stream(side)  # the next step's buffers, and the end of the timed region, wait for the frame
             t1.record()
             torch.cuda.synchronize()
             gather_ms[0] += t0.elapsed_time(t1)
 
+    def all_stats():
+        for r in live:
+            r.synchronize()
+        sts = [r.stats() for r in live]
+        return {k: sum(getattr(st, k) for st in sts) for k in ("paths", "trace_ms", "shade_ms", "closest_hit_scans", "shaded_vertices")}
+
     for _ in range(args.warmup):
         step()
     barrier()
-    r.synchronize()
-    st0 = r.stats()
+    st0 = all_stats()
     gather_ms[0] = 0.0
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t_start
-    r.synchronize()
-    st1 = r.stats()
-    batch_spp = r.batch_spp()
+    st1 = all_stats()
+    batch_spp = live[0].batch_spp()
+    block_pixels = blocks[0].rows * W
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if staging else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # kernel time from HIP events recorded by the library on the launch stream (timed region only)
-    paths_rank = st1.paths - st0.paths
-    trace_ms = st1.trace_ms - st0.trace_ms
-    shade_ms = st1.shade_ms - st0.shade_ms
-    v_int = (st1.closest_hit_scans - st0.closest_hit_scans) / max(paths_rank, 1)
-    v_shade = (st1.shaded_vertices - st0.shaded_vertices) / max(paths_rank, 1)
+    paths_rank = st1["paths"] - st0["paths"]
+    trace_ms = st1["trace_ms"] - st0["trace_ms"]
+    shade_ms = st1["shade_ms"] - st0["shade_ms"]
+    v_int = (st1["closest_hit_scans"] - st0["closest_hit_scans"]) / max(paths_rank, 1)
+    v_shade = (st1["shaded_vertices"] - st0["shaded_vertices"]) / max(paths_rank, 1)
 
     if rank == 0:
         total_paths = W * H * args.spp * args.steps
@@ -183,7 +229,7 @@ def main():
         dominant = "shade" if shade_ms >= trace_ms else "trace"
         dom_ms = max(shade_ms, trace_ms)
         # per launch: paths per kernel launch and its average duration (launches = batches)
-        paths_per_launch = batch_spp * n_tile
+        paths_per_launch = batch_spp * block_pixels
         launches = max(1, round(paths_rank / max(paths_per_launch, 1)))
         avg_launch_ms = dom_ms / launches
         achieved = model[dominant] * paths_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
@@ -203,7 +249,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cornell_plane_light.scn %dx%d, %d spp, depth %d (BASELINE configs[1])" % (W, H, args.spp, args.depth),
                        "film": "full spectral (sum+filter, mean, variance x %d wavelengths)" % S,
-                       "partition": "rows cyclic over %d rank(s), one gather of the film per step" % world,
+                       "partition": "rows cyclic over %d rank(s) in %d row block(s); each block's film gathered to rank 0 while the next renders" % (world, len(blocks)),
                        "paths_per_step": W * H * args.spp},
             "roofline": {"bound": "hbm", "kernel": "drt_%s_kernel" % dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -218,11 +264,19 @@ def main():
                                  "traffic = HBM bytes per launch of that kernel from the committed rocprofv3 PMC profile (profiles/traffic.json), when it matches"},
         }
         if world > 1:
-            out["gather_ms_per_step"] = round(gather_ms[0] / args.steps, 3)
+            out["gather_ms_per_step"] = round(gather_ms[0] / args.steps, 3)  # the part not hidden behind rendering
+        if args.checksum:
+            # wrap-around int64 sum of the bit patterns: exact and independent of the order of pixels
+            if world == 1:
+                for fb in blocks:
+                    fb.finish()
+            torch.cuda.synchronize()
+            out["frame_checksum"] = [int(t.view(torch.int64).sum().item()) for t in blocks[0].image]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(lambda: pydrt.load_scene(scene_file, W, H), W, H, args.depth)
         print(json.dumps(out))
-    r.close()
+    for r in live:
+        r.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -139,6 +139,7 @@ struct TraceParams
     uint64_t n_pix, n_paths;
     uint32_t vertex_words, path_words; /* record strides in 8-byte words (path_words = max_depth * vertex_words) */
     uint32_t hits_sample_offset, batch;  /* batch = sample slots per pixel in the record arrays */
+    uint32_t chunk, pad0;                /* path ids a wave draws from the work counter at a time (multiple of 64) */
 };
 
 struct EvalCoef
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
     const uint32_t lane = threadIdx.x & 63u;
     /* per-wave work queue: a wave draws chunks of consecutive path ids from the global counter and
      * deals them to its idle lanes by ballot + prefix count */
-    const uint64_t CHUNK = 64ull * 16ull;
+    const uint64_t CHUNK = tp.chunk;
     uint64_t chunk_next = 0, chunk_end = 0; /* wave-uniform */
 
     uint32_t n_scans = 0, n_shaded = 0, n_shadow = 0, n_draws = 0, n_paths = 0;
@@ -829,7 +830,10 @@ struct ShadeParams
     uint32_t n_samples, first_sample, vertex_words, path_words;
     uint32_t n_lights, batch;
     uint32_t tail_first, tail_count; /* wavelengths [tail_first, tail_first + tail_count) go through the packed tail pass (0: none) */
-    uint32_t chunk, pad0;            /* pixels per work chunk (= tail group size when there is a tail) */
+    uint32_t chunk, sub_pixels;      /* pixels per group (= tail packing size when there is a tail); pixels per main-pass work item */
+    uint32_t tail_period_mains, pad1;  /* split queue with a tail: main-pass items between two tail items (<= main items per group) */
+    uint32_t items_per_group, n_items; /* work items: per group of `chunk` pixels, ceil(chunk/sub_pixels) main-pass items and, with a tail,
+                                          one tail-pass item; items_per_group == 1: one item does the group's main pass and then its tail */
 };
 
 __device__ __forceinline__ double word_as_double(uint64_t w) { return __longlong_as_double((long long)w); }
@@ -957,14 +961,55 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
     const uint32_t S_main = sp.tail_count ? sp.tail_first : S; /* wavelengths the lane-per-wavelength pass covers */
     for (;;)
     {
-        /* draw the next chunk of pixels (wave-uniform) */
-        unsigned long long chunk_base = 0;
-        if (lane == 0) chunk_base = atomicAdd(work_counter, (unsigned long long)sp.chunk);
-        chunk_base = readlane64(chunk_base, 0);
-        if (chunk_base >= sp.n_pix) break;
+        /* draw the next work item (wave-uniform): part of a pixel group's main pass, its tail pass, or both */
+        uint32_t item = 0;
+        if (lane == 0) item = (uint32_t)atomicAdd(work_counter, 1ull);
+        item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+        if (item >= sp.n_items) break;
+        /* split queue: a group's tail pass is the longest item, so the tail items are dealt out early -- one at the head of
+         * every period of 1 + tail_period_mains items, between main-pass pieces so that latency-bound tail waves and
+         * arithmetic-bound main waves share the SIMDs -- and the launch ends on main-pass pieces only */
+        const bool split = sp.items_per_group > 1;
+        const uint32_t mains_per_group = sp.items_per_group - (sp.tail_count ? 1u : 0u);
+        bool tail_item = sp.tail_count != 0;
+        uint32_t group = item, sub = 0;
+        if (split)
+        {
+            uint32_t m = item; /* index among the main-pass pieces */
+            if (sp.tail_count)
+            {
+                const uint32_t n_groups = sp.n_items / sp.items_per_group;
+                const uint32_t q = sp.tail_period_mains, mixed = n_groups * (q + 1u);
+                if (item < mixed)
+                {
+                    const uint32_t period = item / (q + 1u), r = item - period * (q + 1u);
+                    tail_item = r == 0u;
+                    group = period;
+                    m = period * q + (r - 1u);
+                }
+                else
+                {
+                    tail_item = false;
+                    m = n_groups * q + (item - mixed);
+                }
+            }
+            if (!tail_item)
+            {
+                group = m / mains_per_group;
+                sub = m - group * mains_per_group;
+            }
+        }
+        const uint64_t chunk_base = (uint64_t)group * sp.chunk;
         const uint64_t chunk_end = (chunk_base + sp.chunk < sp.n_pix) ? chunk_base + sp.chunk : sp.n_pix;
+        uint64_t main_base = chunk_base, main_end = chunk_end;
+        if (split)
+        {
+            main_base = chunk_base + (uint64_t)sub * sp.sub_pixels;
+            main_end = (main_base + sp.sub_pixels < chunk_end) ? main_base + sp.sub_pixels : chunk_end;
+            if (tail_item || main_base > chunk_end) main_base = main_end = chunk_end; /* nothing for the main pass */
+        }
 
-      for (uint64_t pix = chunk_base; pix < chunk_end; pix += 1)
+      for (uint64_t pix = main_base; pix < main_end; pix += 1)
       {
 
         double *px = film_pixels + pix * (uint64_t)(S + 1);
@@ -980,27 +1025,30 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
             f_avg[k] = active ? pa[lam] : 0.0;
             f_var[k] = active ? pv[lam] : 0.0;
         }
-        /* headers of all the pixel's samples in one coalesced load: lane s <- sample s */
+        /* the pixel's samples in windows of 64: the headers of a window arrive in one coalesced load, lane s <- sample s */
+      for (uint32_t s0 = 0; s0 < sp.n_samples; s0 += 64u)
+      {
+        const uint32_t n_win = (sp.n_samples - s0 < 64u) ? sp.n_samples - s0 : 64u;
         uint64_t h0 = 0, h1 = 0;
-        if (lane < sp.n_samples)
+        if (lane < n_win)
         {
-            const uint64_t *h = headers + (pix * sp.batch + lane) * REC_HEADER_WORDS;
+            const uint64_t *h = headers + (pix * sp.batch + s0 + lane) * REC_HEADER_WORDS;
             h0 = h[0];
             h1 = h[1];
         }
-        const uint64_t *rbase = records + pix * (uint64_t)sp.batch * sp.path_words;
+        const uint64_t *rbase = records + (pix * (uint64_t)sp.batch + s0) * sp.path_words;
         /* ring of prefetched records: ring[0] = the sample being replayed, ring[d] = d samples ahead. Memory
          * latency (~2 us) is several samples of replay, so the loads run SHADE_PREFETCH_DEPTH samples ahead. */
         uint64_t ring[SHADE_PREFETCH_DEPTH + 1][SHADE_PREFETCH_REGS];
 #pragma unroll
         for (int d = 0; d < SHADE_PREFETCH_DEPTH; d += 1)
         {
-            const uint32_t nw = ((uint32_t)d < sp.n_samples) ? (uint32_t)(readlane64(h0, d) & 0xFFFFu) * vw : 0u;
+            const uint32_t nw = ((uint32_t)d < n_win) ? (uint32_t)(readlane64(h0, d) & 0xFFFFu) * vw : 0u;
             const uint64_t *p = rbase + (uint64_t)d * sp.path_words;
 #pragma unroll
             for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) ring[d + 1][k] = (64u * k + lane < nw) ? p[64u * k + lane] : 0;
         }
-        for (uint32_t s = 0; s < sp.n_samples; s += 1)
+        for (uint32_t s = 0; s < n_win; s += 1)
         {
             const uint64_t hs = readlane64(h0, s);
             const double vignette = word_as_double(readlane64(h1, s));
@@ -1015,7 +1063,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
                 for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) ring[d][k] = ring[d + 1][k];
             {
                 const uint32_t sa = s + SHADE_PREFETCH_DEPTH;
-                const uint32_t nw = (sa < sp.n_samples) ? (uint32_t)(readlane64(h0, sa) & 0xFFFFu) * vw : 0u;
+                const uint32_t nw = (sa < n_win) ? (uint32_t)(readlane64(h0, sa) & 0xFFFFu) * vw : 0u;
                 const uint64_t *p = rbase + (uint64_t)sa * sp.path_words;
 #pragma unroll
                 for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) ring[SHADE_PREFETCH_DEPTH][k] = (64u * k + lane < nw) ? p[64u * k + lane] : 0;
@@ -1165,7 +1213,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
                     throughput[k] = throughput[k] * reflectance; /* :469 */
                 }
             }
-            const double denom = (double)(sp.first_sample + s + 1);
+            const double denom = (double)(sp.first_sample + s0 + s + 1);
 #pragma unroll
             for (int k = 0; k < NSETS; k += 1)
             {
@@ -1186,6 +1234,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
                 f_var[k] = f_var[k] + t0;
             }
         }
+      }
 #pragma unroll
         for (int k = 0; k < NSETS; k += 1)
         {
@@ -1207,7 +1256,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
          * records, read per lane from HBM/L2 (the main pass just touched them), with the same per-wavelength
          * arithmetic in the same order; lanes of different pixels may diverge on material and path length.
          */
-        if (sp.tail_count)
+        if (tail_item)
         {
             const uint32_t R = sp.tail_count;
             const uint32_t g = lane / R, j = lane - g * R;

@@ -17,6 +17,8 @@
 
 static thread_local std::string g_last_error;
 
+#define DRT_DEFAULT_MAX_BATCH 256 /* samples per kernel pair when the caller leaves batch_spp = 0 */
+
 static int fail(int code, const char *fmt, ...)
 {
     char buf[512];
@@ -61,6 +63,7 @@ struct drt_context
     bool   scene_in_lds = true, spds_in_lds = true, use_bvh = false;
     size_t trace_lds = 0, shade_lds = 0;
     int    trace_grid_cap = 0, shade_grid_cap = 0;
+    uint32_t trace_chunk_override = 0, shade_subs_override = ~0u, tail_period_override = 0; /* DRT_TRACE_CHUNK, DRT_SHADE_SUBS tuning knobs */
     uint32_t shade_sets = 1, tail_first = 0, tail_count = 0;
     uint64_t n_pix = 0;
 
@@ -475,10 +478,11 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     uint32_t batch = params->batch_spp;
     if (batch == 0)
     {
-        uint64_t target_paths = 32ull << 20;
-        batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, target_paths / std::max<uint64_t>(ctx->n_pix, 1)));
+        uint64_t target_paths = 64ull << 20;
+        batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(DRT_DEFAULT_MAX_BATCH, target_paths / std::max<uint64_t>(ctx->n_pix, 1)));
+        if (params->spp) batch = std::min(batch, params->spp);
     }
-    batch = std::min<uint32_t>(batch, 64); /* one header lane per sample in the shade kernel */
+    batch = std::min<uint32_t>(batch, 4096);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     size_t film_bytes = (size_t)ctx->n_pix * (3 * (size_t)S + 1) * 8;
@@ -525,6 +529,9 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     if (s_per_cu < 1) s_per_cu = 1;
     if (const char *e = getenv("DRT_SHADE_BLOCKS_PER_CU")) s_per_cu = std::max(1, atoi(e)); /* tuning knob */
     ctx->shade_grid_cap = prop.multiProcessorCount * s_per_cu;
+    if (const char *e = getenv("DRT_TRACE_CHUNK")) ctx->trace_chunk_override = (uint32_t)std::min(1 << 20, std::max(64, atoi(e) / 64 * 64));
+    if (const char *e = getenv("DRT_TAIL_PERIOD")) ctx->tail_period_override = (uint32_t)std::max(0, atoi(e));
+    if (const char *e = getenv("DRT_SHADE_SUBS")) ctx->shade_subs_override = (uint32_t)std::max(0, atoi(e));
     if (getenv("DRT_VERBOSE"))
         fprintf(stderr, "drt: %d CUs, trace %d blocks/CU (lds %zu), shade %d blocks/CU (lds %zu), batch %u, path_words %u\n",
                 prop.multiProcessorCount, per_cu, ctx->trace_lds, s_per_cu, ctx->shade_lds, ctx->batch_spp, ctx->path_words);
@@ -677,6 +684,13 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
         HIP_TRY(hipMemsetAsync(work, 0, 2 * sizeof(unsigned long long), ctx->stream)); /* trace + shade work queues */
         uint64_t blocks_needed = (tp.n_paths + TRACE_BLOCK - 1) / TRACE_BLOCK;
         uint32_t grid = (uint32_t)std::min<uint64_t>(blocks_needed, (uint64_t)ctx->trace_grid_cap);
+        /* work-queue granularity: about 16 draws per wave, so that the last draws finish together; 64..1024 path ids */
+        {
+            uint64_t waves = (uint64_t)grid * (TRACE_BLOCK / 64);
+            uint64_t c = tp.n_paths / (waves * 16) / 64 * 64;
+            tp.chunk = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c, 64), 1024);
+            if (ctx->trace_chunk_override) tp.chunk = ctx->trace_chunk_override;
+        }
         HIP_TRY(hipEventRecord(ev[0], ctx->stream));
         if (ctx->scene_in_lds)
             hipLaunchKernelGGL(drt_trace_kernel<true>, dim3(grid), dim3(TRACE_BLOCK), ctx->trace_lds, ctx->stream, ctx->dsc,
@@ -698,8 +712,43 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
         sp.tail_first = ctx->tail_first;
         sp.tail_count = ctx->tail_count;
         sp.chunk = ctx->tail_count ? 64u / ctx->tail_count : SHADE_PIXEL_CHUNK;
-        uint64_t chunks = (ctx->n_pix + sp.chunk - 1) / sp.chunk;
-        uint32_t sgrid = (uint32_t)std::min<uint64_t>((chunks + SHADE_WAVES - 1) / SHADE_WAVES, (uint64_t)ctx->shade_grid_cap);
+        uint64_t groups = (ctx->n_pix + sp.chunk - 1) / sp.chunk;
+        /* work items: a group's main pass in pieces of sub_pixels pixels (+ its tail pass as an item of its own) when the
+         * groups alone are too few to keep the last round of the persistent waves short */
+        {
+            const uint64_t waves = (uint64_t)ctx->shade_grid_cap * SHADE_WAVES;
+            uint32_t subs = ctx->shade_subs_override;
+            if (subs == ~0u)
+            {
+                /* pixels per main-pass item: small enough for >= 64 items per wave (short last round), large enough for
+                 * >= 256 paths per item (the queue is one atomic counter) */
+                uint64_t p_balance = ctx->n_pix / (waves * 64);
+                uint64_t p_atomic = (256 + n - 1) / n;
+                uint32_t P = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(std::max(p_balance, p_atomic), 1), sp.chunk);
+                subs = (sp.chunk + P - 1) / P;
+                if (subs == 1 && !ctx->tail_count) subs = 0;
+            }
+            subs = std::min(subs, sp.chunk);
+            if (subs == 0 || (subs == 1 && !ctx->tail_count) || groups * (uint64_t)(sp.chunk + 1) >= 0xFFFFFFFFull)
+            {
+                sp.sub_pixels = sp.chunk;
+                sp.items_per_group = 1;
+            }
+            else
+            {
+                sp.sub_pixels = (sp.chunk + subs - 1) / subs;
+                sp.items_per_group = (sp.chunk + sp.sub_pixels - 1) / sp.sub_pixels + (ctx->tail_count ? 1 : 0);
+            }
+            if (groups * sp.items_per_group >= 0xFFFFFFFFull) return fail(-1, "tile too large for the shade work queue");
+            sp.n_items = (uint32_t)(groups * sp.items_per_group);
+            if (ctx->tail_count && sp.items_per_group > 1)
+            {
+                uint32_t mains = sp.items_per_group - 1;
+                sp.tail_period_mains = std::max<uint32_t>(1, mains * 4 / 5); /* the last fifth of the queue is main-pass pieces only */
+                if (ctx->tail_period_override) sp.tail_period_mains = std::min(mains, ctx->tail_period_override);
+            }
+        }
+        uint32_t sgrid = (uint32_t)std::min<uint64_t>(((uint64_t)sp.n_items + SHADE_WAVES - 1) / SHADE_WAVES, (uint64_t)ctx->shade_grid_cap);
         rc = launch_shade(ctx, sgrid, sp);
         if (rc) return rc;
         HIP_TRY(hipGetLastError());

@@ -58,46 +58,99 @@ def render_distributed(render_tile_fn, height, width, rank, world, channels, dst
 
 
 class FilmGather:
-    """The film of a rank as ONE contiguous buffer (sum+filter | mean | variance regions), so reassembling the frame
-    is a single gather with a receive buffer allocated once. Rows are row-cyclic over the ranks."""
+    """The film of a rank -- or of one block of its rows -- as ONE contiguous buffer (sum+filter | mean | variance
+    regions), so that reassembling is a single gather per block with a receive buffer allocated once.
 
-    def __init__(self, height, width, S, rank, world, device, dst=0):
+    Rows are row-cyclic over the ranks: rank r owns image rows r, r + world, ...; its j-th row is y = r + world * j.
+    A block covers the row indices j in [j0, j0 + block_rows) on every rank (fewer on ranks that run out of rows).
+    Rendering block b+1 while block b's gather is in flight (gather_async) hides the transfer behind compute."""
+
+    def __init__(self, height, width, S, rank, world, device, dst=0, j0=0, block_rows=None, image=None):
         self.height, self.width, self.S, self.rank, self.world, self.dst = height, width, S, rank, world, dst
-        self.rows = rank_rows(height, rank, world)[1]
-        self.rows_max = max_tile_rows(height, world)
+        self.j0 = j0
+        self.block_rows = max_tile_rows(height, world) if block_rows is None else block_rows
+        self.rows = self.rows_of(rank)
         self.channels = (S + 1, S, S)
-        n_max = self.rows_max * width
+        n_max = self.block_rows * width
         self.offsets = [0, n_max * (S + 1), n_max * (2 * S + 1)]
         self.flat = torch.zeros(n_max * (3 * S + 1), dtype=torch.float64, device=device)
         self.recv = torch.empty((world, self.flat.numel()), dtype=torch.float64, device=device) if (rank == dst and world > 1) else None
-        self.image = [torch.empty((height, width, c), dtype=torch.float64, device=device) for c in self.channels] if rank == dst else None
+        if rank == dst:
+            self.image = image if image is not None else [torch.empty((height, width, c), dtype=torch.float64, device=device) for c in self.channels]
+        else:
+            self.image = None
+        self._work = None
+        self._staged = None
+
+    def rows_of(self, r):
+        """rows of rank r that fall into this block"""
+        total = rank_rows(self.height, r, self.world)[1]
+        return max(0, min(self.block_rows, total - self.j0))
+
+    def tile(self):
+        """(y0, tile_h, row_stride) of this rank's rows in the block, for drt_params"""
+        return self.rank + self.world * self.j0, self.rows, self.world
 
     def region(self, i):
-        """Film buffer i (0 sum+filter, 1 mean, 2 variance) of this rank's tile: [rows*width, C_i], a view into flat."""
+        """Film buffer i (0 sum+filter, 1 mean, 2 variance) of this rank's rows: [rows*width, C_i], a view into flat."""
         n = self.rows * self.width
         return self.flat[self.offsets[i]: self.offsets[i] + n * self.channels[i]].view(n, self.channels[i])
 
     def zero_(self):
         self.flat.zero_()
 
-    def gather(self, group=None, staging=False):
-        """One collective; returns the three full-frame buffers on dst, None elsewhere."""
+    def gather_async(self, group=None, staging=False):
+        """Start the block's gather (one collective). finish() completes it and places the rows on dst."""
         if self.world == 1:
-            for i in range(3):
-                self.image[i].copy_(self.region(i).view(self.rows, self.width, self.channels[i]))
-            return self.image
+            return
         send = self.flat.cpu() if staging else self.flat
         if self.rank == self.dst:
-            recv = self.recv.cpu() if staging else self.recv
-            dist.gather(send, gather_list=[recv[r] for r in range(self.world)], dst=self.dst, group=group)
-            if staging:
-                self.recv.copy_(recv)
-            for r in range(self.world):
-                rows = rank_rows(self.height, r, self.world)[1]
-                n = rows * self.width
-                for i, c in enumerate(self.channels):
-                    part = self.recv[r, self.offsets[i]: self.offsets[i] + n * c].view(rows, self.width, c)
-                    self.image[i][r::self.world] = part
+            self._staged = self.recv.cpu() if staging else None
+            recv = self._staged if staging else self.recv
+            self._work = dist.gather(send, gather_list=[recv[r] for r in range(self.world)], dst=self.dst, group=group, async_op=True)
+        else:
+            self._work = dist.gather(send, gather_list=None, dst=self.dst, group=group, async_op=True)
+
+    def finish(self):
+        """Wait for the gather, then (dst only) de-interleave the block's rows into the frame. Returns the frame buffers on dst."""
+        if self.world == 1:
+            for i in range(3):
+                self.image[i][self.j0: self.j0 + self.rows] = self.region(i).view(self.rows, self.width, self.channels[i])
             return self.image
-        dist.gather(send, gather_list=None, dst=self.dst, group=group)
-        return None
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        if self.rank != self.dst:
+            return None
+        if self._staged is not None:
+            self.recv.copy_(self._staged)
+            self._staged = None
+        for r in range(self.world):
+            rows = self.rows_of(r)
+            if rows == 0:
+                continue
+            n = rows * self.width
+            y0 = r + self.world * self.j0
+            for i, c in enumerate(self.channels):
+                part = self.recv[r, self.offsets[i]: self.offsets[i] + n * c].view(rows, self.width, c)
+                self.image[i][y0: y0 + self.world * (rows - 1) + 1: self.world] = part
+        return self.image
+
+    def gather(self, group=None, staging=False):
+        """Blocking form: start + finish."""
+        self.gather_async(group=group, staging=staging)
+        return self.finish()
+
+
+def film_blocks(height, width, S, rank, world, device, n_blocks, dst=0):
+    """Split every rank's rows into n_blocks row blocks sharing one frame on dst: [FilmGather, ...]."""
+    rows_max = max_tile_rows(height, world)
+    per = (rows_max + n_blocks - 1) // n_blocks
+    blocks, image = [], None
+    for b in range(n_blocks):
+        if b * per >= rows_max:
+            break
+        fg = FilmGather(height, width, S, rank, world, device, dst=dst, j0=b * per, block_rows=min(per, rows_max - b * per), image=image)
+        image = fg.image
+        blocks.append(fg)
+    return blocks

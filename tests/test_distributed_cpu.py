@@ -50,6 +50,20 @@ def _worker(rank, world, port, height, width, out_path):
             assert torch.equal(a, b)
     else:
         assert flat_full is None
+    # the pipelined form: the rank's rows in 3 blocks, each gathered asynchronously while the next one "renders"
+    blocks = drt_dist.film_blocks(height, width, S, rank, world, torch.device("cpu"), 3)
+    for fb in blocks:
+        by0, brows, bstride = fb.tile()
+        if brows:
+            for i, t in enumerate(render_tile(by0, brows, bstride)):
+                fb.region(i).copy_(t)
+        fb.gather_async()
+    piped = None
+    for fb in blocks:
+        piped = fb.finish()
+    if rank == 0:
+        for a, b in zip(full, piped):
+            assert torch.equal(a, b)
     dist.barrier()
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the max-over-ranks timing reduction bench.py uses

@@ -112,6 +112,41 @@ def test_batching_resume_and_tiles_do_not_change_a_bit():
     assert np.array_equal(tpx.reshape(10, 24, S + 1), full[4:14, 8:32])
 
 
+def test_long_batches_and_work_queue_shapes_do_not_change_a_bit(monkeypatch):
+    """More than 64 samples per kernel pair (the shade kernel walks a pixel's samples in windows of 64) and every shape of
+    the shade work queue (one item per pixel group; main pass in pieces with the tail pass as an item of its own, at several
+    piece sizes and tail spacings) give the same film, bit for bit, and the oracle's."""
+    bundle, _ = cases.load_case("plane_light_16")
+    params = pydrt.make_params(16, 16, spp=150, max_depth=8, seed=3)
+    base = hip_render(bundle, params, batch=32)
+    opx, oav, ova, ohits, _ = O.oracle_render_tile(bundle, params, want_hits=True, math_mode=O.MATH_DEVICE, num_threads=8)
+    assert np.array_equal(base[3], ohits)
+    assert cases.rel_err(base[0], opx) <= FILM_TOL and cases.rel_err(base[1], oav) <= FILM_TOL and cases.rel_err(base[2], ova) <= FILM_TOL
+    for batch in (100, 150, 64, 65):
+        other = hip_render(bundle, params, batch=batch)
+        for a, b in zip(base[:5], other[:5]):
+            assert np.array_equal(a, b), "batch %d" % batch
+    for subs, period in ((0, 0), (1, 0), (3, 1), (5, 2), (12, 0), (12, 12)):
+        monkeypatch.setenv("DRT_SHADE_SUBS", str(subs))
+        monkeypatch.setenv("DRT_TAIL_PERIOD", str(period))
+        monkeypatch.setenv("DRT_TRACE_CHUNK", "64" if subs % 2 else "4096")
+        other = hip_render(bundle, params, batch=70)
+        for a, b in zip(base[:5], other[:5]):
+            assert np.array_equal(a, b), "subs %d period %d" % (subs, period)
+    # a grid without a tail pass (64 wavelengths): pieces of the 16-pixel groups
+    monkeypatch.delenv("DRT_TAIL_PERIOD")
+    b64 = pydrt.load_scene(os.path.join(cases.REPO, "scenes", "cornell_plane_light.scn"), 16, 16, min_wl=380.0, max_wl=695.0, wl_interval=5.0)
+    assert b64.S == 64
+    p64 = pydrt.make_params(16, 16, spp=70, max_depth=8, seed=3)
+    monkeypatch.setenv("DRT_SHADE_SUBS", "0")
+    ref64 = hip_render(b64, p64, batch=70)
+    for subs in (2, 16):
+        monkeypatch.setenv("DRT_SHADE_SUBS", str(subs))
+        other = hip_render(b64, p64, batch=33)
+        for a, b in zip(ref64[:5], other[:5]):
+            assert np.array_equal(a, b), "S=64 subs %d" % subs
+
+
 def test_one_shot_render_tile_accumulates_into_host_buffers():
     bundle, params = cases.load_case("plane_light_16")
     px, av, va, st = pydrt.render_tile(bundle, params)
@@ -200,24 +235,57 @@ def test_full_size_properties_config2():
 
 
 def test_torch_owned_film_and_stream():
-    """PyTorch as plumbing: film tensors allocated by torch, kernels on torch's current stream."""
+    """PyTorch as plumbing: film tensors allocated by torch, kernels on a torch stream. The read-back is enqueued on the
+    same stream with no explicit synchronisation in between, so it is right only if the kernels really ran on that stream
+    (a handle of 0 -- torch's default stream -- would mean "the context's own stream" to drt_set_stream)."""
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.skip("torch sees no GPU")
     bundle, params = cases.load_case("plane_light_48")
     S, n = bundle.S, 48 * 48
     dev = torch.device("cuda:0")
-    t_px = torch.zeros((n, S + 1), dtype=torch.float64, device=dev)
-    t_av = torch.zeros((n, S), dtype=torch.float64, device=dev)
-    t_va = torch.zeros((n, S), dtype=torch.float64, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    assert stream.cuda_stream != 0
     r = pydrt.Renderer(bundle, params)
-    r.bind_film(t_px.data_ptr(), t_av.data_ptr(), t_va.data_ptr())
-    r.set_stream(torch.cuda.current_stream().cuda_stream)
-    r.render()
-    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        t_px = torch.zeros((n, S + 1), dtype=torch.float64, device=dev)
+        t_av = torch.zeros((n, S), dtype=torch.float64, device=dev)
+        t_va = torch.zeros((n, S), dtype=torch.float64, device=dev)
+        r.bind_film(t_px.data_ptr(), t_av.data_ptr(), t_va.data_ptr())
+        r.set_stream(stream.cuda_stream)
+        r.render()
+        h_px = t_px.to("cpu", non_blocking=False)   # ordered after the kernels by the stream alone
+        h_va = t_va.to("cpu", non_blocking=False)
     opx, oav, ova, _, _ = O.oracle_render_tile(bundle, params, math_mode=O.MATH_DEVICE)
-    assert cases.rel_err(t_px.cpu().numpy(), opx) <= FILM_TOL and cases.rel_err(t_va.cpu().numpy(), ova) <= FILM_TOL
+    assert cases.rel_err(h_px.numpy(), opx) <= FILM_TOL and cases.rel_err(h_va.numpy(), ova) <= FILM_TOL
     r.close()
+
+
+def test_bench_two_rank_rehearsal_assembles_the_same_frame():
+    """bench.py's N > 1 path (rows cyclic over ranks, row blocks gathered to rank 0 while the next block renders), rehearsed
+    as two processes sharing this GPU over gloo, assembles bit for bit the frame of the single-process run."""
+    import json
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    bench = os.path.join(cases.REPO, "bench.py")
+    common = ["--size", "96", "--spp", "6", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--checksum"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+
+    def last_json(cmd):
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        return json.loads(lines[0])
+
+    one = last_json([sys.executable, bench] + common)
+    three_blocks = last_json([sys.executable, bench, "--gather-blocks", "3"] + common)
+    assert one["frame_checksum"] == three_blocks["frame_checksum"]
+    two = last_json([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                     "--master-port", "29533", bench, "--gpus", "2", "--backend", "gloo", "--share-device", "--gather-blocks", "3"] + common)
+    assert two["n_gpus"] == 2 and two["frame_checksum"] == one["frame_checksum"]
+    assert two["config"]["paths_per_step"] == 96 * 96 * 6
 
 
 def test_drt_render_program_checkpoint_and_resume(tmp_path):
