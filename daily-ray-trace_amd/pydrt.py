@@ -7,6 +7,7 @@ library is missing, `hip_lib()` raises.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -253,12 +254,36 @@ def plane_from_points(o, pu, pv):
 _hip = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process. A PyTorch-ROCm wheel carries its own libamdhip64.so (soname libamdhip64.so.7, like
+    /opt/rocm's) and loads it by file name; if libdrt_hip.so has pulled in /opt/rocm's copy first, the process ends up with
+    two runtimes and the second one finds no GPU ("No HIP GPUs are available"). So when such a wheel is installed, its copy
+    is loaded first -- without importing torch -- and libdrt_hip.so binds to it by soname; `import torch` later finds the
+    same file already mapped. DRT_NO_TORCH_RUNTIME=1 turns this off (then never import torch after the first render)."""
+    if os.environ.get("DRT_NO_TORCH_RUNTIME") or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def hip_lib():
     global _hip
     if _hip is None:
         path = os.environ.get("DRT_HIP_LIB") or os.path.join(HERE, "libdrt_hip.so")  # DRT_HIP_LIB: A/B builds when profiling
         if not os.path.exists(path):
             raise RuntimeError("libdrt_hip.so is not built (no fallback exists): run __graft_entry__.build()")
+        _share_torch_hip_runtime()
         L = C.CDLL(path)
         L.drt_last_error.restype = C.c_char_p
         L.drt_device_count.restype = C.c_int
