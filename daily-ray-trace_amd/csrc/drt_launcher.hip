@@ -883,6 +883,192 @@ extern "C" int drt_render_tile(const drt_scene *scene, const drt_camera *camera,
     return rc;
 }
 
+/* ---------------------------------------------------------------------------------------------- */
+/* Device groups: one host thread, several GPUs                                                     */
+
+struct drt_group
+{
+    std::vector<drt_context *> ctx; /* nullptr for a device that got no rows */
+    std::vector<uint32_t>      rows;
+    uint32_t tile_w = 0, tile_h = 0, S = 0;
+};
+
+extern "C" void drt_group_destroy(drt_group *g)
+{
+    if (!g) return;
+    std::string keep = g_last_error;
+    for (drt_context *c : g->ctx) drt_destroy(c);
+    delete g;
+    g_last_error = keep;
+}
+
+extern "C" drt_group *drt_group_create(const drt_scene *scene, const drt_camera *camera, const drt_params *params,
+                                       const int32_t *devices, uint32_t n_devices)
+{
+    g_last_error.clear();
+    if (!scene || !camera || !params)
+    {
+        fail(-1, "null argument");
+        return nullptr;
+    }
+    if (n_devices == 0)
+    {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        {
+            (void)hipGetLastError();
+            fail(-5, "no HIP device is visible");
+            return nullptr;
+        }
+        n_devices = (uint32_t)n;
+        devices = nullptr;
+    }
+    if (n_devices > 64)
+    {
+        fail(-1, "more than 64 devices in a group");
+        return nullptr;
+    }
+    if (params->flags & DRT_FLAG_RECORD_HITS)
+    {
+        fail(-1, "hit recording is per context: use drt_create for it");
+        return nullptr;
+    }
+    drt_group *g = new drt_group();
+    g->tile_w = params->tile_w;
+    g->tile_h = params->tile_h;
+    g->S = scene->num_wavelengths;
+    for (uint32_t k = 0; k < n_devices; k += 1)
+    {
+        drt_params p = *params;
+        p.device = devices ? devices[k] : (int32_t)k;
+        p.y0 = params->y0 + k * params->row_stride;
+        p.row_stride = params->row_stride * n_devices;
+        p.tile_h = params->tile_h > k ? (params->tile_h - k + n_devices - 1) / n_devices : 0;
+        g->rows.push_back(p.tile_h);
+        if (p.tile_h == 0)
+        {
+            g->ctx.push_back(nullptr);
+            continue;
+        }
+        drt_context *c = drt_create(scene, camera, &p);
+        if (!c)
+        {
+            drt_group_destroy(g);
+            return nullptr;
+        }
+        g->ctx.push_back(c);
+    }
+    return g;
+}
+
+extern "C" uint32_t drt_group_size(drt_group *g) { return g ? (uint32_t)g->ctx.size() : 0; }
+
+extern "C" int drt_group_render(drt_group *g, uint32_t first_sample, uint32_t num_samples)
+{
+    if (!g) return fail(-1, "null group");
+    for (drt_context *c : g->ctx)
+        if (c)
+        {
+            int rc = drt_render(c, first_sample, num_samples); /* asynchronous: the devices run side by side */
+            if (rc) return rc;
+        }
+    return 0;
+}
+
+extern "C" int drt_group_synchronize(drt_group *g)
+{
+    if (!g) return fail(-1, "null group");
+    for (drt_context *c : g->ctx)
+        if (c)
+        {
+            int rc = drt_synchronize(c);
+            if (rc) return rc;
+        }
+    return 0;
+}
+
+/* rows k, k+n, ... of a whole-tile host buffer <-> device k's contiguous rows: one strided copy */
+static int group_copy(drt_group *g, double *host, int which, bool to_device)
+{
+    if (!host) return 0;
+    const size_t n = g->ctx.size();
+    const size_t C = which == 0 ? (size_t)g->S + 1 : (size_t)g->S;
+    const size_t row_bytes = (size_t)g->tile_w * C * 8;
+    for (size_t k = 0; k < n; k += 1)
+    {
+        drt_context *c = g->ctx[k];
+        if (!c) continue;
+        HIP_TRY(hipSetDevice(c->device));
+        void *dev = which == 0 ? (void *)c->d_pixels : which == 1 ? (void *)c->d_avgs : (void *)c->d_vars;
+        char *h = (char *)host + k * row_bytes;
+        if (to_device)
+            HIP_TRY(hipMemcpy2D(dev, row_bytes, h, n * row_bytes, row_bytes, g->rows[k], hipMemcpyHostToDevice));
+        else
+            HIP_TRY(hipMemcpy2D(h, n * row_bytes, dev, row_bytes, row_bytes, g->rows[k], hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+extern "C" int drt_group_read_film(drt_group *g, double *pixels, double *avgs, double *vars)
+{
+    int rc = drt_group_synchronize(g);
+    if (rc) return rc;
+    if ((rc = group_copy(g, pixels, 0, false))) return rc;
+    if ((rc = group_copy(g, avgs, 1, false))) return rc;
+    return group_copy(g, vars, 2, false);
+}
+
+extern "C" int drt_group_write_film(drt_group *g, const double *pixels, const double *avgs, const double *vars)
+{
+    int rc = drt_group_synchronize(g);
+    if (rc) return rc;
+    if ((rc = group_copy(g, const_cast<double *>(pixels), 0, true))) return rc;
+    if ((rc = group_copy(g, const_cast<double *>(avgs), 1, true))) return rc;
+    return group_copy(g, const_cast<double *>(vars), 2, true);
+}
+
+extern "C" int drt_group_get_stats(drt_group *g, drt_stats *out)
+{
+    if (!g || !out) return fail(-1, "null argument");
+    memset(out, 0, sizeof(*out));
+    for (drt_context *c : g->ctx)
+    {
+        if (!c) continue;
+        drt_stats st;
+        int rc = drt_get_stats(c, &st);
+        if (rc) return rc;
+        out->paths += st.paths;
+        out->closest_hit_scans += st.closest_hit_scans;
+        out->shaded_vertices += st.shaded_vertices;
+        out->shadow_scans += st.shadow_scans;
+        out->rng_draws += st.rng_draws;
+        out->trace_ms = std::max(out->trace_ms, st.trace_ms);
+        out->shade_ms = std::max(out->shade_ms, st.shade_ms);
+        out->total_ms = std::max(out->total_ms, st.total_ms);
+    }
+    return 0;
+}
+
+extern "C" int drt_render_tile_multi(const drt_scene *scene, const drt_camera *camera, const drt_params *params,
+                                     const int32_t *devices, uint32_t n_devices, double *dst_pixels, double *dst_avgs,
+                                     double *dst_vars, drt_stats *stats)
+{
+    g_last_error.clear();
+    if (!dst_pixels || !dst_avgs || !dst_vars) return fail(-1, "null film buffer");
+    drt_group *g = drt_group_create(scene, camera, params, devices, n_devices);
+    if (!g) return -1;
+    int rc = 0;
+    do
+    {
+        if ((rc = drt_group_write_film(g, dst_pixels, dst_avgs, dst_vars))) break;
+        if ((rc = drt_group_render(g, params->first_sample, params->spp))) break;
+        if ((rc = drt_group_read_film(g, dst_pixels, dst_avgs, dst_vars))) break;
+        if (stats && (rc = drt_group_get_stats(g, stats))) break;
+    } while (0);
+    drt_group_destroy(g);
+    return rc;
+}
+
 extern "C" int drt_selftest_arith(int device, int op, const double *a, const double *b, double *out, uint64_t n)
 {
     g_last_error.clear();

@@ -78,7 +78,7 @@ typedef struct
 } spd_file_header;
 
 /* Host extras that the reference has no field for (device choice, RNG seed, batch size);
- * read from the environment by render_image(): DRT_DEVICE, DRT_SEED, DRT_BATCH_SPP, DRT_CHECKPOINT_SPP, DRT_RESUME. */
+ * read from the environment by render_image(): DRT_DEVICE, DRT_DEVICES, DRT_SEED, DRT_BATCH_SPP, DRT_CHECKPOINT_SPP, DRT_RESUME. */
 typedef struct
 {
     int32_t  device;
@@ -87,6 +87,9 @@ typedef struct
     uint32_t quiet;
     uint32_t checkpoint_spp; /* rewrite the .spd files every this many samples (0: only at the end) */
     uint32_t resume;         /* continue from the .spd files of an earlier (checkpointed) run */
+    uint32_t n_devices;      /* > 0: render on devices[0..n_devices) at once, image rows dealt cyclically (drt_group_*); */
+    int32_t  devices[16];    /* 0: the single `device` above. DRT_DEVICES="0,1,2,3" or "all" (every visible device) */
+    uint32_t all_devices;
 } drt_host_options;
 
 /* Fills *config from the text of a config.cfg. Unknown keys are fatal (exit(-1)), like the reference.

@@ -3,8 +3,8 @@
  *
  * Same inputs (config_arguments) and outputs (three .spd files, then the three BMPs of the reference's
  * main()). The `for sample / for y / for x` loop (src/daily_ray_trace.c:710-745) is the C-ABI launcher
- * (include/drt_hip.h: drt_create / drt_render / drt_read_film, the session form of drt_render_tile, so the
- * film can stay on the device between checkpoints); everything around it stays plain C.
+ * (include/drt_hip.h: drt_group_create / drt_group_render / drt_group_read_film, the session form of
+ * drt_render_tile over one or several GPUs, so the film can stay on the device between checkpoints); everything around it stays plain C.
  * There is no CPU fallback: if the launcher fails, render_image reports it and exits.
  */
 #include "drt_host.h"
@@ -128,25 +128,32 @@ int render_image_ex(config_arguments *config, const drt_host_options *opt, drt_s
     }
     f64 t0 = now_ms();
     int rc = 0;
-    drt_context *ctx = drt_create(scene, drt_host_camera_data(hs), &p);
+    /* one device, or several at once with the image rows dealt cyclically over them (one host thread, drt_group_*) */
+    int32_t one_device = p.device;
+    const int32_t *devices = &one_device;
+    u32 n_devices = 1;
+    if (opt && opt->all_devices) { devices = NULL; n_devices = 0; }
+    else if (opt && opt->n_devices) { devices = opt->devices; n_devices = opt->n_devices; }
+    drt_group *ctx = drt_group_create(scene, drt_host_camera_data(hs), &p, devices, n_devices);
     if (!ctx) rc = -1;
-    if (!rc && done) rc = drt_write_film(ctx, dst_pixels, dst_avgs, dst_vars);
+    if (!rc && !(opt && opt->quiet) && drt_group_size(ctx) > 1) printf("Rendering on %u devices\n", drt_group_size(ctx));
+    if (!rc && done) rc = drt_group_write_film(ctx, dst_pixels, dst_avgs, dst_vars);
     u32 step = (opt && opt->checkpoint_spp) ? opt->checkpoint_spp : p.spp;
     while (!rc && done < p.spp)
     {
         u32 n = (p.spp - done < step) ? p.spp - done : step;
-        if ((rc = drt_render(ctx, done, n))) break;
+        if ((rc = drt_group_render(ctx, done, n))) break;
         done += n;
         if (done < p.spp) /* a checkpoint: the final write below uses the same code */
         {
-            if ((rc = drt_read_film(ctx, dst_pixels, dst_avgs, dst_vars))) break;
+            if ((rc = drt_group_read_film(ctx, dst_pixels, dst_avgs, dst_vars))) break;
             if (write_outputs(config, scene, width, height, dst_pixels, dst_avgs, dst_vars, raw_var_path)) fprintf(stderr, "render_image: checkpoint write failed\n");
             if (!(opt && opt->quiet)) printf("Checkpoint at %u / %u samples\n", done, p.spp);
         }
     }
-    if (!rc) rc = drt_read_film(ctx, dst_pixels, dst_avgs, dst_vars);
-    if (!rc) rc = drt_get_stats(ctx, &stats);
-    drt_destroy(ctx);
+    if (!rc) rc = drt_group_read_film(ctx, dst_pixels, dst_avgs, dst_vars);
+    if (!rc) rc = drt_group_get_stats(ctx, &stats);
+    drt_group_destroy(ctx);
     f64 t1 = now_ms();
     if (rc != 0)
     {
@@ -188,6 +195,19 @@ void render_image(config_arguments *config)
     const char *e;
     opt.seed = 1;
     if ((e = getenv("DRT_DEVICE"))) opt.device = atoi(e);
+    if ((e = getenv("DRT_DEVICES")))
+    {
+        if (strcmp(e, "all") == 0) opt.all_devices = 1;
+        else
+            for (const char *c = e; *c && opt.n_devices < 16;)
+            {
+                char *end;
+                long d = strtol(c, &end, 10);
+                if (end == c) break;
+                opt.devices[opt.n_devices++] = (int32_t)d;
+                c = (*end == ',') ? end + 1 : end;
+            }
+    }
     if ((e = getenv("DRT_SEED"))) opt.seed = strtoull(e, NULL, 0);
     if ((e = getenv("DRT_BATCH_SPP"))) opt.batch_spp = (u32)atoi(e);
     if ((e = getenv("DRT_CHECKPOINT_SPP"))) opt.checkpoint_spp = (u32)atoi(e);

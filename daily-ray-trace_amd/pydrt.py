@@ -298,6 +298,20 @@ def hip_lib():
         L.drt_film_device_ptrs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         L.drt_read_film.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.drt_read_xyz.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        f64p, i32p = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        L.drt_group_create.restype = C.c_void_p
+        L.drt_group_create.argtypes = [C.POINTER(Scene), C.POINTER(Camera), C.POINTER(Params), i32p, C.c_uint32]
+        L.drt_group_destroy.argtypes = [C.c_void_p]
+        L.drt_group_destroy.restype = None
+        L.drt_group_size.argtypes = [C.c_void_p]
+        L.drt_group_size.restype = C.c_uint32
+        L.drt_group_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.drt_group_synchronize.argtypes = [C.c_void_p]
+        L.drt_group_read_film.argtypes = [C.c_void_p, f64p, f64p, f64p]
+        L.drt_group_write_film.argtypes = [C.c_void_p, f64p, f64p, f64p]
+        L.drt_group_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.drt_render_tile_multi.argtypes = [C.POINTER(Scene), C.POINTER(Camera), C.POINTER(Params), i32p, C.c_uint32, f64p, f64p, f64p,
+                                            C.POINTER(Stats)]
         L.drt_write_film.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.drt_read_hit_indices.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_uint64]
         L.drt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
@@ -313,7 +327,9 @@ def hip_lib():
 
 HIP_SYMBOLS = ["drt_last_error", "drt_device_count", "drt_create", "drt_destroy", "drt_bind_film", "drt_set_stream",
                "drt_render", "drt_synchronize", "drt_reset_film", "drt_film_device_ptrs", "drt_read_film", "drt_write_film",
-               "drt_read_xyz", "drt_read_hit_indices", "drt_get_stats", "drt_batch_spp", "drt_render_tile", "drt_selftest_arith"]
+               "drt_read_xyz", "drt_read_hit_indices", "drt_get_stats", "drt_batch_spp", "drt_render_tile", "drt_selftest_arith",
+               "drt_group_create", "drt_group_destroy", "drt_group_size", "drt_group_render", "drt_group_synchronize",
+               "drt_group_read_film", "drt_group_write_film", "drt_group_get_stats", "drt_render_tile_multi"]
 
 
 def _check(rc, what):
@@ -396,6 +412,51 @@ class Renderer:
         st = Stats()
         _check(self.L.drt_get_stats(self.ctx, C.byref(st)), "drt_get_stats")
         return st
+
+
+class Group:
+    """drt_group_*: one host thread, several GPUs; the tile's rows dealt cyclically over `devices` (None: all visible)."""
+
+    def __init__(self, bundle, params, devices=None):
+        self.L = hip_lib()
+        self.bundle, self.params, self.S = bundle, params, bundle.S
+        self.n_pixels = int(params.tile_w) * int(params.tile_h)
+        if devices is None:
+            arr, n = None, 0
+        else:
+            arr, n = (C.c_int32 * len(devices))(*devices), len(devices)
+        self.g = self.L.drt_group_create(C.byref(bundle.scene), C.byref(bundle.camera), C.byref(params), arr, n)
+        if not self.g:
+            raise RuntimeError("drt_group_create: " + self.L.drt_last_error().decode())
+
+    def size(self):
+        return int(self.L.drt_group_size(self.g))
+
+    def render(self, first_sample=None, num_samples=None):
+        fs = int(self.params.first_sample) if first_sample is None else first_sample
+        ns = int(self.params.spp) if num_samples is None else num_samples
+        _check(self.L.drt_group_render(self.g, fs, ns), "drt_group_render")
+
+    def read_film(self):
+        px = np.empty((self.n_pixels, self.S + 1)); av = np.empty((self.n_pixels, self.S)); va = np.empty((self.n_pixels, self.S))
+        f64p = C.POINTER(C.c_double)
+        _check(self.L.drt_group_read_film(self.g, px.ctypes.data_as(f64p), av.ctypes.data_as(f64p), va.ctypes.data_as(f64p)), "drt_group_read_film")
+        return px, av, va
+
+    def write_film(self, px, av, va):
+        f64p = C.POINTER(C.c_double)
+        px, av, va = (np.ascontiguousarray(a, dtype=np.float64) for a in (px, av, va))
+        _check(self.L.drt_group_write_film(self.g, px.ctypes.data_as(f64p), av.ctypes.data_as(f64p), va.ctypes.data_as(f64p)), "drt_group_write_film")
+
+    def stats(self):
+        st = Stats()
+        _check(self.L.drt_group_get_stats(self.g, C.byref(st)), "drt_group_get_stats")
+        return st
+
+    def close(self):
+        if self.g:
+            self.L.drt_group_destroy(self.g)
+            self.g = None
 
 
 def render_tile(bundle, params):

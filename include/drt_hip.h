@@ -226,6 +226,33 @@ uint32_t drt_batch_spp(drt_context *ctx);
 int drt_render_tile(const drt_scene *scene, const drt_camera *camera, const drt_params *params,
                     double *dst_pixels, double *dst_avgs, double *dst_vars, drt_stats *stats);
 
+/*
+ * Several GPUs from ONE host thread (SURVEY 8b "Threading": the launcher may drive 1..8 devices, one stream each).
+ * The tile's rows are dealt cyclically over the devices -- device k of n owns tile rows k, k+n, ... for all samples,
+ * the same partition the multi-process callers use -- each device has its own context and stream, all of them render
+ * concurrently, and the film comes back into the caller's buffers in image order (one strided copy per device and
+ * buffer). `devices` lists HIP device ordinals (a device may appear more than once: that many contexts share it);
+ * devices == NULL means 0..n_devices-1, n_devices == 0 means every visible device; drt_params.device is ignored.
+ * Results are bit-identical to a single context's, whatever the device list.
+ */
+typedef struct drt_group drt_group;
+drt_group *drt_group_create(const drt_scene *scene, const drt_camera *camera, const drt_params *params,
+                            const int32_t *devices, uint32_t n_devices);
+void     drt_group_destroy(drt_group *g);
+uint32_t drt_group_size(drt_group *g);
+/* Enqueue samples [first_sample, first_sample+num_samples) on every device. Asynchronous. */
+int drt_group_render(drt_group *g, uint32_t first_sample, uint32_t num_samples);
+int drt_group_synchronize(drt_group *g);
+/* Whole-tile film buffers ([tile_h*tile_w][S+1], [..][S], [..][S]) <-> the devices' row sets. NULL skips a buffer. */
+int drt_group_read_film(drt_group *g, double *pixels, double *avgs, double *vars);
+int drt_group_write_film(drt_group *g, const double *pixels, const double *avgs, const double *vars);
+/* Counters summed over the devices; trace_ms / shade_ms / total_ms are the slowest device's. */
+int drt_group_get_stats(drt_group *g, drt_stats *out);
+/* One-shot form of drt_render_tile over a device list. */
+int drt_render_tile_multi(const drt_scene *scene, const drt_camera *camera, const drt_params *params,
+                          const int32_t *devices, uint32_t n_devices,
+                          double *dst_pixels, double *dst_avgs, double *dst_vars, drt_stats *stats);
+
 /* Arithmetic self-test kernels: evaluate op over n inputs on the device so tests can check
  * that f64 sqrt / divide / the path's sincos are bit-identical to the host. op: 0 sqrt(a),
  * 1 a/b, 2 sincos(a) -> out[2*i], out[2*i+1], 3 pow(a,b), 4 rng stream from key a (as u64 bits). */

@@ -147,6 +147,51 @@ def test_long_batches_and_work_queue_shapes_do_not_change_a_bit(monkeypatch):
             assert np.array_equal(a, b), "S=64 subs %d" % subs
 
 
+def test_device_group_gives_the_single_context_film():
+    """drt_group_*: one host thread, several contexts (here 1, 3 and 5 of them, all on GPU 0; 5 > the 4 rows of the last
+    tile, so one context gets no rows) with the rows dealt cyclically -- film, resume and statistics equal the single
+    context's bit for bit; the one-shot drt_render_tile_multi accumulates into host buffers like drt_render_tile."""
+    bundle, params = cases.load_case("plane_light_48")
+    base = hip_render(bundle, params, record_hits=False)
+    for devices in ([0], [0, 0, 0], [0] * 5):
+        g = pydrt.Group(bundle, params, devices)
+        assert g.size() == len(devices)
+        g.render(0, 1)
+        g.render(1, int(params.spp) - 1)
+        px, av, va = g.read_film()
+        st = g.stats()
+        g.close()
+        assert np.array_equal(px, base[0]) and np.array_equal(av, base[1]) and np.array_equal(va, base[2])
+        assert (st.paths, st.closest_hit_scans, st.shaded_vertices, st.rng_draws) == \
+               (base[5].paths, base[5].closest_hit_scans, base[5].shaded_vertices, base[5].rng_draws)
+    # a tile with fewer rows than devices, with a row stride of its own, written and read back through the group
+    pt = pydrt.make_params(48, 48, spp=4, max_depth=8, seed=1, x0=5, y0=1, tile_w=30, tile_h=4, row_stride=11)
+    ref = hip_render(bundle, pt, record_hits=False)
+    g = pydrt.Group(bundle, pt, [0] * 5)
+    g.render(0, 2)
+    half = g.read_film()
+    g.close()
+    g = pydrt.Group(bundle, pt, [0, 0])
+    g.write_film(*half)
+    g.render(2, 2)
+    px, av, va = g.read_film()
+    g.close()
+    assert np.array_equal(px, ref[0]) and np.array_equal(av, ref[1]) and np.array_equal(va, ref[2])
+    # one-shot form
+    L = pydrt.hip_lib()
+    f64p = C.POINTER(C.c_double)
+    S, n = bundle.S, 48 * 48
+    px = np.zeros((n, S + 1)); av = np.zeros((n, S)); va = np.zeros((n, S))
+    st = pydrt.Stats()
+    devs = (C.c_int32 * 2)(0, 0)
+    rc = L.drt_render_tile_multi(C.byref(bundle.scene), C.byref(bundle.camera), C.byref(params), devs, 2, px.ctypes.data_as(f64p),
+                                 av.ctypes.data_as(f64p), va.ctypes.data_as(f64p), C.byref(st))
+    assert rc == 0, L.drt_last_error()
+    assert np.array_equal(px, base[0]) and np.array_equal(va, base[2]) and st.paths == base[5].paths
+    with pytest.raises(RuntimeError):
+        pydrt.Group(bundle, params, [0, 99])
+
+
 def test_one_shot_render_tile_accumulates_into_host_buffers():
     bundle, params = cases.load_case("plane_light_16")
     px, av, va, st = pydrt.render_tile(bundle, params)
@@ -372,6 +417,13 @@ def test_drt_render_program_checkpoint_and_resume(tmp_path):
     assert "Resuming after 4 samples" in out2
     for f in ("output.spd", "average.spd", "variance.spd", "output.bmp"):
         assert open(os.path.join(a, "output", f), "rb").read() == open(os.path.join(b, "output", f), "rb").read(), f
+    # the same program driving several contexts at once (rows dealt over the device list; here all on GPU 0), checkpointed too
+    c = str(tmp_path / "c")
+    os.makedirs(c)
+    out3 = run(c, 6, {"DRT_DEVICES": "0,0,0", "DRT_CHECKPOINT_SPP": "4"})
+    assert "Rendering on 3 devices" in out3 and "Checkpoint at 4 / 6 samples" in out3
+    for f in ("output.spd", "average.spd", "variance.spd", "output.bmp"):
+        assert open(os.path.join(a, "output", f), "rb").read() == open(os.path.join(c, "output", f), "rb").read(), f
     # and the film agrees with the oracle
     hdr = np.fromfile(os.path.join(a, "output", "output.spd"), dtype=np.uint32, count=5)
     assert list(hdr[1:5]) == [96, 64, 69, 1]
