@@ -197,6 +197,12 @@ def main():
         sts = [r.stats() for r in live]
         return {k: sum(getattr(st, k) for st in sts) for k in ("paths", "trace_ms", "shade_ms", "closest_hit_scans", "shaded_vertices")}
 
+    if world > 1:
+        # set up the communicator and its point-to-point connections (made lazily on first use) outside the timed region,
+        # whatever --warmup is: one gather of the same shape as a block's
+        blocks[0].gather_async(staging=staging)
+        finish_on_side(blocks[0])
+        stream.wait_stream(side)
     for _ in range(args.warmup):
         step()
     barrier()
