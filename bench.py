@@ -140,8 +140,11 @@ def main():
         if brows == 0:
             renderers.append(None)
             continue
+        # contexts live across all the steps, so launches are sized for throughput (64 M paths per kernel pair, drt_hip.h), not
+        # for the one frame `spp` announces
+        batch = args.batch if args.batch > 0 else max(1, min(256, args.spp, (64 << 20) // max(brows * W, 1)))
         params = pydrt.make_params(W, H, spp=args.spp, max_depth=args.depth, seed=1, y0=by0, tile_h=brows, row_stride=bstride,
-                                   device=local_rank, batch_spp=args.batch)
+                                   device=local_rank, batch_spp=batch)
         r = pydrt.Renderer(bundle, params)
         r.bind_film(fb.region(0).data_ptr(), fb.region(1).data_ptr(), fb.region(2).data_ptr())
         r.set_stream(block_streams[b % len(block_streams)].cuda_stream)

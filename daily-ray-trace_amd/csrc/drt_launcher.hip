@@ -13,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <chrono>
 #include <vector>
 
 static thread_local std::string g_last_error;
@@ -474,12 +475,20 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     if (ctx->dsc.n_spd >= 0xFFFFu) return fail(-2, "too many SPDs for the 16-bit record indices");
     if (S > 64 * SHADE_MAX_SETS) return fail(-2, "more than %d wavelengths", 64 * SHADE_MAX_SETS);
 
-    /* batch: enough paths in flight to fill the chip many times over, bounded record memory */
+    /* batch (samples per kernel pair): large launches are the efficient ones (their last round is amortised: DESIGN.md,
+     * work queues), but the record buffer grows with them and device memory a process touches for the first time is
+     * cleared by the driver -- 10-40 ms per GB, seconds for the 68 GB that suit a long-lived context. So the default
+     * follows the job the caller announces in params->spp: about 32 kernel pairs per job, at least 1 GB of records, at
+     * most 64 M paths per launch. Callers that keep a context across many frames pass batch_spp themselves. */
     uint32_t batch = params->batch_spp;
     if (batch == 0)
     {
-        uint64_t target_paths = 64ull << 20;
-        batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(DRT_DEFAULT_MAX_BATCH, target_paths / std::max<uint64_t>(ctx->n_pix, 1)));
+        const uint64_t npx = std::max<uint64_t>(ctx->n_pix, 1);
+        const uint64_t path_bytes = (uint64_t)ctx->path_words * 8;
+        uint64_t by_job = (std::max<uint32_t>(params->spp, 1) + 31) / 32;
+        uint64_t by_floor = (1ull << 30) / (path_bytes * npx);
+        uint64_t cap = std::max<uint64_t>(1, std::min<uint64_t>(DRT_DEFAULT_MAX_BATCH, (64ull << 20) / npx));
+        batch = (uint32_t)std::max<uint64_t>(1, std::min(std::max(by_job, by_floor), cap));
         if (params->spp) batch = std::min(batch, params->spp);
     }
     batch = std::min<uint32_t>(batch, 4096);
@@ -861,25 +870,42 @@ extern "C" int drt_get_stats(drt_context *ctx, drt_stats *out)
 
 extern "C" uint32_t drt_batch_spp(drt_context *ctx) { return ctx ? ctx->batch_spp : 0; }
 
+static double wall_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
 extern "C" int drt_render_tile(const drt_scene *scene, const drt_camera *camera, const drt_params *params,
                                double *dst_pixels, double *dst_avgs, double *dst_vars, drt_stats *stats)
 {
     g_last_error.clear();
     if (!dst_pixels || !dst_avgs || !dst_vars) return fail(-1, "null film buffer");
+    const bool verbose = getenv("DRT_VERBOSE") != nullptr || getenv("DRT_TIMING") != nullptr;
+    double t[6] = {wall_ms(), 0, 0, 0, 0, 0};
     drt_context *ctx = drt_create(scene, camera, params);
     if (!ctx) return -1;
+    t[1] = wall_ms();
     int rc = 0;
     do
     {
-        /* accumulate INTO the caller's buffers: start from their contents */
-        if ((rc = drt_write_film(ctx, dst_pixels, dst_avgs, dst_vars))) break;
+        /* accumulate INTO the caller's buffers: start from their contents (unless the caller vouches they are zero) */
+        if (!(params->flags & DRT_FLAG_FILM_ZERO) && (rc = drt_write_film(ctx, dst_pixels, dst_avgs, dst_vars))) break;
+        t[2] = wall_ms();
         if ((rc = drt_render(ctx, params->first_sample, params->spp))) break;
+        if (verbose && (rc = drt_synchronize(ctx))) break;
+        t[3] = wall_ms();
         if ((rc = drt_read_film(ctx, dst_pixels, dst_avgs, dst_vars))) break;
         if (stats && (rc = drt_get_stats(ctx, stats))) break;
+        t[4] = wall_ms();
     } while (0);
     std::string keep = g_last_error;
     drt_destroy(ctx);
     g_last_error = keep;
+    t[5] = wall_ms();
+    if (verbose && rc == 0)
+        fprintf(stderr, "drt_render_tile: create %.1f ms, film upload %.1f ms, render %.1f ms, film download %.1f ms, destroy %.1f ms\n",
+                t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4]);
     return rc;
 }
 
@@ -1060,7 +1086,7 @@ extern "C" int drt_render_tile_multi(const drt_scene *scene, const drt_camera *c
     int rc = 0;
     do
     {
-        if ((rc = drt_group_write_film(g, dst_pixels, dst_avgs, dst_vars))) break;
+        if (!(params->flags & DRT_FLAG_FILM_ZERO) && (rc = drt_group_write_film(g, dst_pixels, dst_avgs, dst_vars))) break;
         if ((rc = drt_group_render(g, params->first_sample, params->spp))) break;
         if ((rc = drt_group_read_film(g, dst_pixels, dst_avgs, dst_vars))) break;
         if (stats && (rc = drt_group_get_stats(g, stats))) break;

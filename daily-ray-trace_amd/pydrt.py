@@ -19,6 +19,7 @@ GEO_POINT, GEO_SPHERE, GEO_PLANE = 1, 2, 3
 FILM_SAMPLE_CENTER, FILM_SAMPLE_RANDOM = 1, 2
 MODE_SPECTRAL, MODE_XYZ = 0, 1
 FLAG_RECORD_HITS = 1
+FLAG_FILM_ZERO = 2
 
 # names and order of include/bdsf_list.h
 BDSF_NAMES = ["bp_diffuse_bdsf", "bp_glossy_bdsf", "mirror_bdsf", "fs_conductor_bdsf",

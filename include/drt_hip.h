@@ -160,13 +160,17 @@ typedef struct drt_params
     uint64_t seed;
     uint32_t mode;         /* DRT_MODE_* */
     int32_t  device;       /* HIP device ordinal */
-    uint32_t batch_spp;    /* samples traced per launch pair (0 = library default) */
+    uint32_t batch_spp;    /* samples traced per launch pair. 0 = sized for a job of `spp` samples (about 32 launch pairs, >= 1 GB of
+                              path records); a context kept across many frames does better with 64 M paths per launch:
+                              batch_spp = min(256, (64 << 20) / (tile_w * tile_h)) */
     uint32_t flags;        /* DRT_FLAG_* */
 } drt_params;
 
 enum
 {
-    DRT_FLAG_RECORD_HITS = 1u /* keep closest-hit surface indices per path vertex (parity tests) */
+    DRT_FLAG_RECORD_HITS = 1u, /* keep closest-hit surface indices per path vertex (parity tests) */
+    DRT_FLAG_FILM_ZERO   = 2u  /* one-shot forms only: the caller's buffers are zero-filled (as the reference's alloc() leaves
+                                  them, src/daily_ray_trace.c:689-691), so they are not uploaded before rendering */
 };
 
 typedef struct drt_stats

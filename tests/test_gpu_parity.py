@@ -210,6 +210,14 @@ def test_one_shot_render_tile_accumulates_into_host_buffers():
     o8 = O.oracle_render_tile(bundle, p8, math_mode=O.MATH_DEVICE)
     assert cases.rel_err(px, o8[0]) <= FILM_TOL and cases.rel_err(av, o8[1]) <= FILM_TOL and cases.rel_err(va, o8[2]) <= FILM_TOL
     assert np.all(px[:, bundle.S] == 8.0)
+    # DRT_FLAG_FILM_ZERO: the caller vouches for zero-filled buffers, nothing is uploaded -- same film as the plain call
+    pz = pydrt.make_params(16, 16, spp=4, max_depth=8, seed=1, flags=pydrt.FLAG_FILM_ZERO)
+    zx = np.zeros_like(px); za = np.zeros_like(av); zv = np.zeros_like(va)
+    rc = L.drt_render_tile(C.byref(bundle.scene), C.byref(bundle.camera), C.byref(pz), zx.ctypes.data_as(f64p), za.ctypes.data_as(f64p),
+                           zv.ctypes.data_as(f64p), C.byref(st2))
+    assert rc == 0
+    o4 = O.oracle_render_tile(bundle, params, math_mode=O.MATH_DEVICE)
+    assert cases.rel_err(zx, o4[0]) <= FILM_TOL and cases.rel_err(zv, o4[2]) <= FILM_TOL
 
 
 def test_errors_are_reported_not_swallowed():
