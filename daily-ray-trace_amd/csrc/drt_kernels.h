@@ -61,8 +61,17 @@ enum
 struct BvhNode
 {
     double  lo[2][3], hi[2][3]; /* the two children's boxes */
-    int32_t child[2];           /* inner child: node index; leaf child: first slot in bvh_prims */
+    int32_t child[2];           /* inner child: node index; leaf child: first slot in bvh_leaf */
     int32_t count[2];           /* 0: inner child, > 0: leaf with that many surfaces, < 0: no child */
+    int32_t pad[4];             /* 128 bytes: a node is one cache line */
+};
+
+/* A surface as the leaves see it: its SoA fields gathered into one 128-byte record, records of a leaf adjacent -- a
+ * lane walking the tree on its own touches one cache line per sphere instead of one per field. */
+struct BvhLeafPrim
+{
+    uint32_t index, type;
+    double   f[SF_COUNT];
 };
 
 struct DevMaterial
@@ -92,7 +101,7 @@ struct DevScene
     const DevMaterial *mats;       /* [n_mat] */
     const double      *spds;       /* [n_spd][S]: scene rows, derived diffuse/pi rows, one zero row */
     const BvhNode     *bvh_nodes;  /* NULL: scan every surface */
-    const uint32_t    *bvh_prims;  /* surface indices, grouped by leaf */
+    const BvhLeafPrim *bvh_leaf;   /* the surfaces grouped by leaf */
 };
 
 struct DevCamera
@@ -162,7 +171,7 @@ struct SceneView /* pointers into LDS (or HBM when the scene does not fit) */
     const uint32_t    *light_type, *light_mat;
     const DevMaterial *mats;
     const BvhNode     *bvh_nodes;
-    const uint32_t    *bvh_prims;
+    const BvhLeafPrim *bvh_leaf;
     uint32_t           n_surf, n_lights;
 };
 
@@ -180,6 +189,13 @@ __device__ __forceinline__ double surface_distance(const SceneView &sv, uint32_t
 
 #define BVH_STACK 48
 
+__device__ __forceinline__ double leaf_distance(const BvhLeafPrim &lp, V3 o, V3 d)
+{
+    if (lp.type == DRT_GEO_SPHERE) return line_sphere(o, d, v3(lp.f[SF_PX], lp.f[SF_PY], lp.f[SF_PZ]), lp.f[SF_RADIUS]);
+    return line_plane(o, d, v3(lp.f[SF_PX], lp.f[SF_PY], lp.f[SF_PZ]), v3(lp.f[SF_NX], lp.f[SF_NY], lp.f[SF_NZ]),
+                      v3(lp.f[SF_UNX], lp.f[SF_UNY], lp.f[SF_UNZ]), v3(lp.f[SF_VNX], lp.f[SF_VNY], lp.f[SF_VNZ]), lp.f[SF_ULEN], lp.f[SF_VLEN]);
+}
+
 /* ray vs padded box: entry distance, or a negative number when the box is missed / behind the ray */
 __device__ __forceinline__ double bvh_box_entry(const BvhNode &n, int c, V3 o, V3 inv_d)
 {
@@ -192,93 +208,137 @@ __device__ __forceinline__ double bvh_box_entry(const BvhNode &n, int c, V3 o, V
     return tmin > 0.0 ? tmin : 0.0;
 }
 
+/* Traversal state: a reference is an inner node index (>= 0), a leaf (< BVH_DONE: first slot and count packed), or
+ * BVH_DONE. Both loops are "while-while" (Aila & Laine): every lane first walks inner nodes until it holds a leaf,
+ * then the wave tests leaf surfaces together -- box tests and surface tests are not interleaved lane by lane, which is
+ * what kept 5 lanes in 6 idle in the one-loop form (rocprofv3: SQ_THREAD_CYCLES_VALU / 64 SQ_ACTIVE_INST_VALU = 17 %). */
+#define BVH_DONE (-1)
+__device__ __forceinline__ int bvh_leaf_ref(int first, int count) { return -2 - (first * 8 + (count - 1)); } /* count 1..8 */
+__device__ __forceinline__ bool bvh_is_leaf(int ref) { return ref < BVH_DONE; }
+
+/* the two children of inner node `node` against the ray: which are entered within `limit`, and where */
+__device__ __forceinline__ void bvh_children(const BvhNode &n, V3 o, V3 inv_d, double limit, bool strict, int ref[2], double t[2], bool hit[2])
+{
+#pragma unroll
+    for (int c = 0; c < 2; c += 1)
+    {
+        const int cnt = n.count[c];
+        t[c] = bvh_box_entry(n, c, o, inv_d);
+        hit[c] = cnt >= 0 && t[c] >= 0.0 && (strict ? t[c] < limit : t[c] <= limit);
+        ref[c] = cnt > 0 ? bvh_leaf_ref(n.child[c], cnt) : n.child[c];
+    }
+}
+
 /* closest hit through the hierarchy: min distance, lowest index on ties */
 __device__ __forceinline__ void bvh_closest(const SceneView &sv, V3 o, V3 d, double &min_dist, int &index)
 {
-    V3 inv_d = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-    int stack[BVH_STACK];
+    const V3 inv_d = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    int   stack[BVH_STACK];
+    float stack_t[BVH_STACK]; /* entry distance of the pushed subtree, rounded DOWN: a later, nearer hit culls it on pop */
     int sp = 0;
-    int node = 0;
+    int cur = 0;
     for (;;)
     {
-        const BvhNode &n = sv.bvh_nodes[node];
-        int next = -1;
-        double next_t = 0.0;
-        for (int c = 0; c < 2; c += 1)
+        while (cur >= 0) /* inner nodes */
         {
-            int cnt = n.count[c];
-            if (cnt < 0) continue;
-            double t = bvh_box_entry(n, c, o, inv_d);
-            if (t < 0.0 || t > min_dist) continue;
-            if (cnt > 0)
+            const BvhNode &n = sv.bvh_nodes[cur];
+            int ref[2];
+            double t[2];
+            bool hit[2];
+            bvh_children(n, o, inv_d, min_dist, false, ref, t, hit);
+            if (hit[0] && hit[1])
             {
-                for (int k = 0; k < cnt; k += 1)
+                const int near = t[1] < t[0] ? 1 : 0; /* nearer box first */
+                if (sp < BVH_STACK)
                 {
-                    uint32_t i = sv.bvh_prims[n.child[c] + k];
-                    double dist = surface_distance(sv, i, sv.surf_type[i], o, d);
-                    if (dist < min_dist || (dist == min_dist && (int)i < index))
+                    stack[sp] = ref[1 - near];
+                    stack_t[sp] = __double2float_rd(t[1 - near]);
+                    sp += 1;
+                }
+                cur = ref[near];
+            }
+            else if (hit[0]) cur = ref[0];
+            else if (hit[1]) cur = ref[1];
+            else
+            {
+                cur = BVH_DONE;
+                while (sp > 0)
+                {
+                    sp -= 1;
+                    if (!((double)stack_t[sp] > min_dist))
                     {
-                        min_dist = dist;
-                        index = (int)i;
+                        cur = stack[sp];
+                        break;
                     }
                 }
             }
-            else if (next < 0)
+        }
+        if (cur == BVH_DONE) break;
+        while (bvh_is_leaf(cur)) /* leaves */
+        {
+            const int packed = -2 - cur;
+            const int first = packed >> 3, count = (packed & 7) + 1;
+            for (int k = 0; k < count; k += 1)
             {
-                next = n.child[c];
-                next_t = t;
-            }
-            else if (sp < BVH_STACK)
-            {
-                /* two inner children: descend into the nearer one first */
-                if (t < next_t)
+                const BvhLeafPrim &lp = sv.bvh_leaf[first + k];
+                double dist = leaf_distance(lp, o, d);
+                if (dist < min_dist || (dist == min_dist && (int)lp.index < index))
                 {
-                    stack[sp++] = next;
-                    next = n.child[c];
-                    next_t = t;
+                    min_dist = dist;
+                    index = (int)lp.index;
                 }
-                else stack[sp++] = n.child[c];
+            }
+            cur = BVH_DONE;
+            while (sp > 0)
+            {
+                sp -= 1;
+                if (!((double)stack_t[sp] > min_dist))
+                {
+                    cur = stack[sp];
+                    break;
+                }
             }
         }
-        if (next >= 0) node = next;
-        else if (sp > 0) node = stack[--sp];
-        else break;
+        if (cur == BVH_DONE) break;
     }
 }
 
 /* any surface nearer than vis_dist? (the shadow test; order does not matter for a yes/no answer) */
 __device__ __forceinline__ bool bvh_occluded(const SceneView &sv, V3 o, V3 d, double vis_dist)
 {
-    V3 inv_d = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    const V3 inv_d = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     int stack[BVH_STACK];
     int sp = 0;
-    int node = 0;
+    int cur = 0;
     for (;;)
     {
-        const BvhNode &n = sv.bvh_nodes[node];
-        int next = -1;
-        for (int c = 0; c < 2; c += 1)
+        while (cur >= 0)
         {
-            int cnt = n.count[c];
-            if (cnt < 0) continue;
-            double t = bvh_box_entry(n, c, o, inv_d);
-            if (t < 0.0 || !(t < vis_dist)) continue;
-            if (cnt > 0)
+            const BvhNode &n = sv.bvh_nodes[cur];
+            int ref[2];
+            double t[2];
+            bool hit[2];
+            bvh_children(n, o, inv_d, vis_dist, true, ref, t, hit);
+            if (hit[0] && hit[1])
             {
-                for (int k = 0; k < cnt; k += 1)
-                {
-                    uint32_t i = sv.bvh_prims[n.child[c] + k];
-                    if (surface_distance(sv, i, sv.surf_type[i], o, d) < vis_dist) return true;
-                }
+                if (sp < BVH_STACK) stack[sp++] = ref[1];
+                cur = ref[0];
             }
-            else if (next < 0) next = n.child[c];
-            else if (sp < BVH_STACK) stack[sp++] = n.child[c];
+            else if (hit[0]) cur = ref[0];
+            else if (hit[1]) cur = ref[1];
+            else cur = sp > 0 ? stack[--sp] : BVH_DONE;
         }
-        if (next >= 0) node = next;
-        else if (sp > 0) node = stack[--sp];
-        else break;
+        if (cur == BVH_DONE) return false;
+        while (bvh_is_leaf(cur))
+        {
+            const int packed = -2 - cur;
+            const int first = packed >> 3, count = (packed & 7) + 1;
+            for (int k = 0; k < count; k += 1)
+                if (leaf_distance(sv.bvh_leaf[first + k], o, d) < vis_dist) return true;
+            cur = sp > 0 ? stack[--sp] : BVH_DONE;
+        }
+        if (cur == BVH_DONE) return false;
     }
-    return false;
 }
 
 /* points_mutually_visible, src/daily_ray_trace.c:238-270 */
@@ -593,7 +653,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
         sv.light_mat = l_u32 + 2 * sc.n_surf + sc.n_lights;
         sv.mats = l_mats;
         sv.bvh_nodes = nullptr; /* a scene that fits LDS is scanned whole */
-        sv.bvh_prims = nullptr;
+        sv.bvh_leaf = nullptr;
     }
     else
     {
@@ -605,7 +665,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
         sv.light_mat = sc.light_mat;
         sv.mats = sc.mats;
         sv.bvh_nodes = sc.bvh_nodes;
-        sv.bvh_prims = sc.bvh_prims;
+        sv.bvh_leaf = sc.bvh_leaf;
     }
 
     const uint32_t lane = threadIdx.x & 63u;

@@ -133,7 +133,7 @@ struct BvhBuilder
     std::vector<BuildPrim> prims;
     std::vector<BvhNode>   nodes;
     std::vector<uint32_t>  order;
-    static const int LEAF = 4;
+    int LEAF = 4; /* surfaces per leaf (<= 8: the traversal packs the count in 3 bits) */
 
     void bounds(size_t b, size_t e, double lo[3], double hi[3]) const
     {
@@ -146,7 +146,7 @@ struct BvhBuilder
             }
     }
     /* fills child slot c of node `parent` with the subtree over prims [b, e) */
-    void set_child(int parent, int c, size_t b, size_t e)
+    void set_child(int parent, int c, size_t b, size_t e, int depth)
     {
         double lo[3], hi[3];
         bounds(b, e, lo, hi);
@@ -162,10 +162,19 @@ struct BvhBuilder
         nodes.push_back(BvhNode());
         nodes[parent].child[c] = me;
         nodes[parent].count[c] = 0;
-        split(me, b, e);
+        split(me, b, e, depth + 1);
     }
-    void split(int node, size_t b, size_t e)
+    static double half_area(const double lo[3], const double hi[3])
     {
+        double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    /* Binned surface-area heuristic (32 bins per axis, all three axes): the split that minimises
+     * area(left)*n(left) + area(right)*n(right); falls back to the median along the widest axis when the
+     * centroids do not separate. Only the amount of pruning depends on this, never a result. */
+    void split(int node, size_t b, size_t e, int depth)
+    {
+        const int BINS = 32;
         double clo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, chi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
         for (size_t i = b; i < e; i += 1)
             for (int k = 0; k < 3; k += 1)
@@ -173,13 +182,75 @@ struct BvhBuilder
                 clo[k] = std::min(clo[k], prims[i].c[k]);
                 chi[k] = std::max(chi[k], prims[i].c[k]);
             }
-        int axis = 0;
-        for (int k = 1; k < 3; k += 1) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
-        size_t mid = (b + e) / 2;
-        std::nth_element(prims.begin() + b, prims.begin() + mid, prims.begin() + e,
-                         [axis](const BuildPrim &x, const BuildPrim &y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx); });
-        set_child(node, 0, b, mid);
-        set_child(node, 1, mid, e);
+        int best_axis = -1, best_bin = -1;
+        double best_cost = HUGE_VAL;
+        /* SAH trees have no depth bound of their own; the traversal stack holds BVH_STACK (48) entries, one per level at most:
+         * below level 24 the median split takes over, which adds at most log2(n) levels */
+        if (!getenv("DRT_BVH_MEDIAN") && depth < 24)
+            for (int axis = 0; axis < 3; axis += 1)
+            {
+                double ext = chi[axis] - clo[axis];
+                if (!(ext > 0.0)) continue;
+                double blo[BINS][3], bhi[BINS][3];
+                size_t cnt[BINS];
+                for (int k = 0; k < BINS; k += 1)
+                {
+                    cnt[k] = 0;
+                    for (int a = 0; a < 3; a += 1) { blo[k][a] = HUGE_VAL; bhi[k][a] = -HUGE_VAL; }
+                }
+                for (size_t i = b; i < e; i += 1)
+                {
+                    int k = std::min(BINS - 1, (int)((prims[i].c[axis] - clo[axis]) / ext * BINS));
+                    cnt[k] += 1;
+                    for (int a = 0; a < 3; a += 1)
+                    {
+                        blo[k][a] = std::min(blo[k][a], prims[i].lo[a]);
+                        bhi[k][a] = std::max(bhi[k][a], prims[i].hi[a]);
+                    }
+                }
+                /* sweep: right-side areas from the back, then left side from the front */
+                double r_area[BINS];
+                size_t r_cnt[BINS];
+                double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+                size_t n = 0;
+                for (int k = BINS - 1; k > 0; k -= 1)
+                {
+                    if (cnt[k]) for (int a = 0; a < 3; a += 1) { lo[a] = std::min(lo[a], blo[k][a]); hi[a] = std::max(hi[a], bhi[k][a]); }
+                    n += cnt[k];
+                    r_area[k] = n ? half_area(lo, hi) : 0.0;
+                    r_cnt[k] = n;
+                }
+                for (int a = 0; a < 3; a += 1) { lo[a] = HUGE_VAL; hi[a] = -HUGE_VAL; }
+                n = 0;
+                for (int k = 0; k + 1 < BINS; k += 1) /* split after bin k */
+                {
+                    if (cnt[k]) for (int a = 0; a < 3; a += 1) { lo[a] = std::min(lo[a], blo[k][a]); hi[a] = std::max(hi[a], bhi[k][a]); }
+                    n += cnt[k];
+                    if (n == 0 || r_cnt[k + 1] == 0) continue;
+                    double cost = half_area(lo, hi) * (double)n + r_area[k + 1] * (double)r_cnt[k + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = k; }
+                }
+            }
+        size_t mid;
+        if (best_axis >= 0)
+        {
+            const int axis = best_axis, bin = best_bin;
+            const double lo0 = clo[axis], ext = chi[axis] - clo[axis];
+            auto it = std::stable_partition(prims.begin() + b, prims.begin() + e, [=](const BuildPrim &x) {
+                return std::min(BINS - 1, (int)((x.c[axis] - lo0) / ext * BINS)) <= bin;
+            });
+            mid = (size_t)(it - prims.begin());
+        }
+        else
+        {
+            int axis = 0;
+            for (int k = 1; k < 3; k += 1) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+            mid = (b + e) / 2;
+            std::nth_element(prims.begin() + b, prims.begin() + mid, prims.begin() + e,
+                             [axis](const BuildPrim &x, const BuildPrim &y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx); });
+        }
+        set_child(node, 0, b, mid, depth);
+        set_child(node, 1, mid, e, depth);
     }
     void build(const drt_scene *scene)
     {
@@ -197,8 +268,8 @@ struct BvhBuilder
         nodes[0].count[0] = nodes[0].count[1] = -1;
         nodes[0].child[0] = nodes[0].child[1] = 0;
         if (prims.empty()) return;
-        if (prims.size() <= (size_t)LEAF) set_child(0, 0, 0, prims.size());
-        else split(0, 0, prims.size());
+        if (prims.size() <= (size_t)LEAF) set_child(0, 0, 0, prims.size(), 0);
+        else split(0, 0, prims.size(), 0);
     }
 };
 
@@ -370,14 +441,23 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene)
     if (getenv("DRT_NO_BVH")) ctx->use_bvh = false; /* tuning knob: brute-force scan from HBM */
     else ctx->use_bvh = !ctx->scene_in_lds;
     d.bvh_nodes = nullptr;
-    d.bvh_prims = nullptr;
+    d.bvh_leaf = nullptr;
     if (ctx->use_bvh)
     {
         BvhBuilder bb;
+        if (const char *e = getenv("DRT_BVH_LEAF")) bb.LEAF = std::min(8, std::max(1, atoi(e))); /* tuning knob */
         bb.build(scene);
-        if (bb.order.empty()) bb.order.push_back(0);
+        std::vector<BvhLeafPrim> leaf(std::max<size_t>(bb.order.size(), 1));
+        memset(leaf.data(), 0, leaf.size() * sizeof(BvhLeafPrim));
+        for (size_t k = 0; k < bb.order.size(); k += 1)
+        {
+            const uint32_t i = bb.order[k];
+            leaf[k].index = i;
+            leaf[k].type = stype[i];
+            for (int f = 0; f < SF_COUNT; f += 1) leaf[k].f[f] = surf[(size_t)f * n_surf + i];
+        }
         if ((rc = upload(ctx, bb.nodes, &d.bvh_nodes))) return rc;
-        if ((rc = upload(ctx, bb.order, &d.bvh_prims))) return rc;
+        if ((rc = upload(ctx, leaf, &d.bvh_leaf))) return rc;
     }
     if (!ctx->scene_in_lds) ctx->trace_lds = 0;
     ctx->spds_in_lds = (size_t)d.n_spd * S * 8 <= 64 * 1024;

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.join(REPO, "daily-ray-trace_amd"))
 import pydrt
 spp = int(os.environ.get("SPP", "16")); batch = int(os.environ.get("BATCH", "8")); size = int(os.environ.get("SIZE", "1024"))
 depth = int(os.environ.get("DEPTH", "8"))
-bundle = pydrt.load_scene(os.path.join(REPO, "scenes", "cornell_plane_light.scn"), size, size)
+spheres = int(os.environ.get("SPHERES", "0"))  # > 0: BASELINE config 5's generator instead of the Cornell box
+bundle = pydrt.synthetic_sphere_scene(spheres, size, size) if spheres else pydrt.load_scene(os.path.join(REPO, "scenes", "cornell_plane_light.scn"), size, size)
 params = pydrt.make_params(size, size, spp=spp, max_depth=depth, seed=1, batch_spp=batch)
 r = pydrt.Renderer(bundle, params)
 r.render(0, batch); r.synchronize(); r.reset_film()
