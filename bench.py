@@ -6,8 +6,9 @@ Metric (BASELINE.json): Mpaths/s (pixels*spp/s), Cornell 1024^2, depth 8 -- corn
 
 A "step" is one full render of that frame: every sample of every pixel through the trace and the shade+film
 kernels, with scene, SPD tables and film resident in HBM when the clock starts. With N > 1 GPUs the frame is
-tiled row-cyclically over the ranks (one process per GPU) and each step ends with the single gather of the
-three film buffers to rank 0 over RCCL; total work is fixed, so scaling is "strong".
+tiled row-cyclically over the ranks (one process per GPU); a rank renders its rows in row blocks and each block's
+film (three buffers, one contiguous allocation) is gathered to rank 0 over RCCL while the next block renders; the
+step ends when the whole frame is assembled on rank 0. Total work is fixed, so scaling is "strong".
 
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -258,7 +259,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cornell_plane_light.scn %dx%d, %d spp, depth %d (BASELINE configs[1])" % (W, H, args.spp, args.depth),
                        "film": "full spectral (sum+filter, mean, variance x %d wavelengths)" % S,
-                       "partition": "rows cyclic over %d rank(s) in %d row block(s); each block's film gathered to rank 0 while the next renders" % (world, len(blocks)),
+                       "partition": ("whole frame on one GPU" if world == 1 and len(blocks) == 1 else
+                                     "rows cyclic over %d rank(s) in %d row block(s); each block's film gathered to rank 0 while the next renders" % (world, len(blocks))),
                        "paths_per_step": W * H * args.spp},
             "roofline": {"bound": "hbm", "kernel": "drt_%s_kernel" % dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -984,11 +984,12 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
  * cast_ray's spectral side (src/daily_ray_trace.c:440-472 with direct_light_contribution :272-332
  * inlined), the vignette (:615) and render_image's film update (:732-743) on accumulators kept in
  * registers. The film is read and written once per batch. Waves are persistent (SPD tables staged
- * into LDS once) and draw chunks of pixels from a global counter, because pixel cost varies.
+ * into LDS once) and draw work items (pixel groups, or pieces of them: see the queue below) from a global counter,
+ * because pixel cost varies.
  */
 #define SHADE_PREFETCH_REGS 2 /* 64-word registers per path: 128 record words are prefetched, deeper paths fall back */
 #define SHADE_PREFETCH_DEPTH 3 /* samples whose record loads are in flight ahead of the one being replayed */
-#define SHADE_PIXEL_CHUNK 16 /* default pixels per work chunk */
+#define SHADE_PIXEL_CHUNK 16 /* pixels per group when there is no tail pass (with one: 64 / tail wavelengths) */
 
 template <int NSETS, bool SPDS_IN_LDS>
 __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_shade_kernel(DevScene sc, ShadeParams sp, const uint64_t *__restrict__ records,

@@ -1,4 +1,5 @@
-"""Multi-GPU framebuffer tiling: one process per GPU, no exchange during rendering, one gather at the end.
+"""Multi-GPU framebuffer tiling: one process per GPU, no exchange during rendering, the film gathered to rank 0
+(whole, or block by block behind the rendering of the next block: FilmGather / film_blocks).
 
 Partition: row-cyclic -- rank r owns image rows r, r+N, r+2N, ... for all samples, so the
 per-pixel running mean/variance state stays local and the 61 %-escape imbalance of the Cornell frame is
