@@ -134,6 +134,10 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
+    if world > 1:
+        # the kernels are persistent and fill the chip: leave a few workgroup slots free so that the gather of the previous block
+        # (RCCL's kernels) and rank 0's de-interleave copies start at once instead of at the next kernel boundary
+        os.environ.setdefault("DRT_RESERVE_BLOCKS", "16")
     block_streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(max(1, args.block_streams) - 1)]
     renderers = []
     for b, fb in enumerate(blocks):

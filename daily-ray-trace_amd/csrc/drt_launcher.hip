@@ -618,6 +618,15 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     if (s_per_cu < 1) s_per_cu = 1;
     if (const char *e = getenv("DRT_SHADE_BLOCKS_PER_CU")) s_per_cu = std::max(1, atoi(e)); /* tuning knob */
     ctx->shade_grid_cap = prop.multiProcessorCount * s_per_cu;
+    /* Both grids are persistent and fill every wave slot of the chip, so a kernel of another stream -- a collective's,
+     * a copy's -- starts only when one of them ends. DRT_RESERVE_BLOCKS=n leaves n workgroup slots free for such
+     * company (bench.py sets it when a gather runs behind the rendering). */
+    if (const char *e = getenv("DRT_RESERVE_BLOCKS"))
+    {
+        int n = std::max(0, atoi(e));
+        ctx->trace_grid_cap = std::max(1, ctx->trace_grid_cap - n);
+        ctx->shade_grid_cap = std::max(1, ctx->shade_grid_cap - n);
+    }
     if (const char *e = getenv("DRT_TRACE_CHUNK")) ctx->trace_chunk_override = (uint32_t)std::min(1 << 20, std::max(64, atoi(e) / 64 * 64));
     if (const char *e = getenv("DRT_TAIL_PERIOD")) ctx->tail_period_override = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("DRT_SHADE_SUBS")) ctx->shade_subs_override = (uint32_t)std::max(0, atoi(e));
