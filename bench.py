@@ -30,14 +30,14 @@ sys.path.insert(0, os.path.join(REPO, "daily-ray-trace_amd"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def algorithmic_bytes(S, v_int, v_shade):
+def algorithmic_bytes(S, v_int, v_shade, xyz=False):
     """SURVEY 8d byte model per path, split by kernel.
     B_film = 2*8*(S+1) + 2*8*S + 2*8*S           sum(+filter), mean, variance read-modify-write
     B_state = 2*(48 + 8*S + 4 + 8 + 4)            ray, throughput spectrum, pixel id, rng, depth: per closest-hit iteration
     B_rad = 2*8*S                                 radiance spectrum RMW per shaded vertex
     The spectral part (film, radiance, throughput spectrum) is the shade kernel's; the ray/rng/id state is the
     trace kernel's."""
-    b_film = 2 * 8 * (S + 1) + 2 * 8 * S + 2 * 8 * S
+    b_film = 48 if xyz else 2 * 8 * (S + 1) + 2 * 8 * S + 2 * 8 * S  # XYZ-only film: 48 B (SURVEY 8d)
     b_state = 2 * (48 + 8 * S + 4 + 8 + 4)
     b_rad = 2 * 8 * S
     shade = b_film + v_shade * b_rad + v_int * (2 * 8 * S)
@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="samples per kernel pair (0 = library default)")
     ap.add_argument("--gather-blocks", type=int, default=0, help="row blocks per rank (0 = 1 at N=1, 4 at N>1)")
     ap.add_argument("--block-streams", type=int, default=1, help="HIP streams the row blocks are spread over (blocks on different streams overlap)")
+    ap.add_argument("--film", default="spectral", choices=["spectral", "xyz"],
+                    help="spectral = the reference's film (the headline metric); xyz = DRT_MODE_XYZ, a different mode, labelled as such")
     ap.add_argument("--checksum", action="store_true", help="add an order-independent checksum of the assembled frame to the JSON line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
@@ -127,7 +129,8 @@ def main():
     # with its own render context; block b's gather to rank 0 is in flight while block b+1 renders.
     # Blocks of >= 128k pixels keep the kernels' last rounds short; at least 2 so a gather can hide.
     n_blocks = args.gather_blocks if args.gather_blocks > 0 else (max(2, min(8, n_tile // (128 * 1024))) if world > 1 else 1)
-    blocks = drt_dist.film_blocks(H, W, S, rank, world, dev, n_blocks)
+    xyz = args.film == "xyz"
+    blocks = drt_dist.film_blocks(H, W, S, rank, world, dev, n_blocks, channels=(8,) if xyz else None)
     # One explicit (non-default) stream carries the film zero-fill, the kernels, the collectives' dependencies and the
     # de-interleave copies. The default stream's handle is 0, which drt_set_stream() reads as "the context's own stream":
     # the gather would then not wait for the render.
@@ -149,9 +152,12 @@ def main():
         # for the one frame `spp` announces
         batch = args.batch if args.batch > 0 else max(1, min(256, args.spp, (64 << 20) // max(brows * W, 1)))
         params = pydrt.make_params(W, H, spp=args.spp, max_depth=args.depth, seed=1, y0=by0, tile_h=brows, row_stride=bstride,
-                                   device=local_rank, batch_spp=batch)
+                                   device=local_rank, batch_spp=batch, mode=pydrt.MODE_XYZ if xyz else pydrt.MODE_SPECTRAL)
         r = pydrt.Renderer(bundle, params)
-        r.bind_film(fb.region(0).data_ptr(), fb.region(1).data_ptr(), fb.region(2).data_ptr())
+        if xyz:
+            r.bind_film(fb.region(0).data_ptr(), None, None)
+        else:
+            r.bind_film(fb.region(0).data_ptr(), fb.region(1).data_ptr(), fb.region(2).data_ptr())
         r.set_stream(block_streams[b % len(block_streams)].cuda_stream)
         renderers.append(r)
     live = [r for r in renderers if r is not None]
@@ -239,7 +245,7 @@ def main():
     if rank == 0:
         total_paths = W * H * args.spp * args.steps
         value = total_paths / elapsed / 1e6
-        model = algorithmic_bytes(S, v_int, v_shade)
+        model = algorithmic_bytes(S, v_int, v_shade, xyz)
         dominant = "shade" if shade_ms >= trace_ms else "trace"
         dom_ms = max(shade_ms, trace_ms)
         # per launch: paths per kernel launch and its average duration (launches = batches)
@@ -249,7 +255,7 @@ def main():
         achieved = model[dominant] * paths_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not xyz:
             try:
                 tj = json.load(open(tpath))
                 if tj.get("workload") == "cornell_plane_light %dx%d depth %d" % (W, H, args.depth):
@@ -257,12 +263,13 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "Mpaths/s (pixels*spp/s) Cornell 1024^2 depth 8; achieved HBM GB/s % of peak",
+            "metric": "Mpaths/s (pixels*spp/s) Cornell 1024^2 depth 8; achieved HBM GB/s % of peak" + (" [XYZ-only film: NOT the headline mode]" if xyz else ""),
             "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cornell_plane_light.scn %dx%d, %d spp, depth %d (BASELINE configs[1])" % (W, H, args.spp, args.depth),
-                       "film": "full spectral (sum+filter, mean, variance x %d wavelengths)" % S,
+                       "film": ("XYZ only (DRT_MODE_XYZ: 8 accumulators per pixel, no mean/variance)" if xyz else
+                                "full spectral (sum+filter, mean, variance x %d wavelengths)" % S),
                        "partition": ("whole frame on one GPU" if world == 1 and len(blocks) == 1 else
                                      "rows cyclic over %d rank(s) in %d row block(s); each block's film gathered to rank 0 while the next renders" % (world, len(blocks))),
                        "paths_per_step": W * H * args.spp},

@@ -891,6 +891,7 @@ struct ShadeParams
     uint32_t n_lights, batch;
     uint32_t tail_first, tail_count; /* wavelengths [tail_first, tail_first + tail_count) go through the packed tail pass (0: none) */
     uint32_t chunk, sub_pixels;      /* pixels per group (= tail packing size when there is a tail); pixels per main-pass work item */
+    uint32_t cmf_rw, cmf_x, cmf_y, cmf_z; /* XYZ film mode: SPD rows of the white table and the colour-matching functions */
     uint32_t tail_period_mains, pad1;  /* split queue with a tail: main-pass items between two tail items (<= main items per group) */
     uint32_t items_per_group, n_items; /* work items: per group of `chunk` pixels, ceil(chunk/sub_pixels) main-pass items and, with a tail,
                                           one tail-pass item; items_per_group == 1: one item does the group's main pass and then its tail */
@@ -991,7 +992,9 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
 #define SHADE_PREFETCH_DEPTH 3 /* samples whose record loads are in flight ahead of the one being replayed */
 #define SHADE_PIXEL_CHUNK 16 /* pixels per group when there is no tail pass (with one: 64 / tail wavelengths) */
 
-template <int NSETS, bool SPDS_IN_LDS>
+#define XYZ_FILM_WORDS 8 /* XYZ film mode, per pixel: X, Y, Z numerators of the main pass, filter sum, X, Y, Z of the tail pass, unused */
+
+template <int NSETS, bool SPDS_IN_LDS, bool XYZ>
 __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_shade_kernel(DevScene sc, ShadeParams sp, const uint64_t *__restrict__ records,
                                                                  const uint64_t *__restrict__ headers, double *__restrict__ film_pixels,
                                                                  double *__restrict__ film_avgs, double *__restrict__ film_vars,
@@ -1073,18 +1076,20 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
       for (uint64_t pix = main_base; pix < main_end; pix += 1)
       {
 
-        double *px = film_pixels + pix * (uint64_t)(S + 1);
-        double *pa = film_avgs + pix * (uint64_t)S;
-        double *pv = film_vars + pix * (uint64_t)S;
+        /* spectral film: the pixel's [S+1] / [S] / [S] rows; XYZ film: its XYZ_FILM_WORDS accumulators, and the batch's
+         * spectral sum starts from zero and is folded into them at the end */
+        double *px = film_pixels + pix * (uint64_t)(XYZ ? XYZ_FILM_WORDS : S + 1);
+        double *pa = XYZ ? nullptr : film_avgs + pix * (uint64_t)S;
+        double *pv = XYZ ? nullptr : film_vars + pix * (uint64_t)S;
         double f_sum[NSETS], f_avg[NSETS], f_var[NSETS];
 #pragma unroll
         for (int k = 0; k < NSETS; k += 1)
         {
             const uint32_t lam = 64u * k + lane;
             const bool active = lam < S_main;
-            f_sum[k] = active ? px[lam] : 0.0;
-            f_avg[k] = active ? pa[lam] : 0.0;
-            f_var[k] = active ? pv[lam] : 0.0;
+            f_sum[k] = (active && !XYZ) ? px[lam] : 0.0;
+            f_avg[k] = (active && !XYZ) ? pa[lam] : 0.0;
+            f_var[k] = (active && !XYZ) ? pv[lam] : 0.0;
         }
         /* the pixel's samples in windows of 64: the headers of a window arrive in one coalesced load, lane s <- sample s */
       for (uint32_t s0 = 0; s0 < sp.n_samples; s0 += 64u)
@@ -1286,28 +1291,65 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
                 const double contribution = dst[k] * vignette; /* :615 */
                 /* film update, src/daily_ray_trace.c:732-743 */
                 f_sum[k] = f_sum[k] + contribution;
-                double t0 = contribution - f_avg[k];
-                double t1 = t0;
-                t0 = t0 / denom;
-                f_avg[k] = f_avg[k] + t0;
-                t0 = contribution - f_avg[k];
-                t0 = t1 * t0;
-                f_var[k] = f_var[k] + t0;
+                if (!XYZ)
+                {
+                    double t0 = contribution - f_avg[k];
+                    double t1 = t0;
+                    t0 = t0 / denom;
+                    f_avg[k] = f_avg[k] + t0;
+                    t0 = contribution - f_avg[k];
+                    t0 = t1 * t0;
+                    f_var[k] = f_var[k] + t0;
+                }
             }
         }
       }
-#pragma unroll
-        for (int k = 0; k < NSETS; k += 1)
+        if (XYZ)
         {
-            const uint32_t lam = 64u * k + lane;
-            if (lam < S_main)
+            /* spectrum_to_xyz's sums (src/spectrum.c:58-66) over this batch's spectral sum: per lane, then across the wave */
+            const double *table = SPDS_IN_LDS ? (const double *)lds : sc.spds;
+            double X = 0.0, Y = 0.0, Z = 0.0;
+#pragma unroll
+            for (int k = 0; k < NSETS; k += 1)
             {
-                px[lam] = f_sum[k];
-                pa[lam] = f_avg[k];
-                pv[lam] = f_var[k];
+                const uint32_t lam = 64u * k + lane;
+                if (lam < S_main)
+                {
+                    const double rw = spd_at(table, S, sp.cmf_rw, lam);
+                    X += (spd_at(table, S, sp.cmf_x, lam) * f_sum[k] * rw);
+                    Y += (spd_at(table, S, sp.cmf_y, lam) * f_sum[k] * rw);
+                    Z += (spd_at(table, S, sp.cmf_z, lam) * f_sum[k] * rw);
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1)
+            {
+                X += __shfl_xor(X, off);
+                Y += __shfl_xor(Y, off);
+                Z += __shfl_xor(Z, off);
+            }
+            if (lane == 0)
+            {
+                px[0] += X;
+                px[1] += Y;
+                px[2] += Z;
+                px[3] += (double)sp.n_samples * 1.0;
             }
         }
-        if (lane == 0) px[S] += (double)sp.n_samples * 1.0; /* filter sum: += 1.0 per sample, :733 */
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < NSETS; k += 1)
+            {
+                const uint32_t lam = 64u * k + lane;
+                if (lam < S_main)
+                {
+                    px[lam] = f_sum[k];
+                    pa[lam] = f_avg[k];
+                    pv[lam] = f_var[k];
+                }
+            }
+            if (lane == 0) px[S] += (double)sp.n_samples * 1.0; /* filter sum: += 1.0 per sample, :733 */
+        }
       }
 
         /*
@@ -1325,10 +1367,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
             const bool act = g < (uint32_t)(chunk_end - chunk_base) && g < 64u / R;
             const uint32_t lam = sp.tail_first + j; /* < S by construction */
             const double *table = SPDS_IN_LDS ? (const double *)lds : sc.spds;
-            double *px = film_pixels + pix_l * (uint64_t)(S + 1);
-            double *pa = film_avgs + pix_l * (uint64_t)S;
-            double *pv = film_vars + pix_l * (uint64_t)S;
-            double f_sum = act ? px[lam] : 0.0, f_avg = act ? pa[lam] : 0.0, f_var = act ? pv[lam] : 0.0;
+            double *px = film_pixels + pix_l * (uint64_t)(XYZ ? XYZ_FILM_WORDS : S + 1);
+            double *pa = XYZ ? nullptr : film_avgs + pix_l * (uint64_t)S;
+            double *pv = XYZ ? nullptr : film_vars + pix_l * (uint64_t)S;
+            double f_sum = (act && !XYZ) ? px[lam] : 0.0, f_avg = (act && !XYZ) ? pa[lam] : 0.0, f_var = (act && !XYZ) ? pv[lam] : 0.0;
             for (uint32_t s = 0; s < sp.n_samples; s += 1)
             {
                 const uint64_t slot = pix_l * sp.batch + s;
@@ -1407,15 +1449,40 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
                 const double contribution = dst * word_as_double(h1);
                 const double denom = (double)(sp.first_sample + s + 1);
                 f_sum = f_sum + contribution;
-                double t0 = contribution - f_avg;
-                double t1 = t0;
-                t0 = t0 / denom;
-                f_avg = f_avg + t0;
-                t0 = contribution - f_avg;
-                t0 = t1 * t0;
-                f_var = f_var + t0;
+                if (!XYZ)
+                {
+                    double t0 = contribution - f_avg;
+                    double t1 = t0;
+                    t0 = t0 / denom;
+                    f_avg = f_avg + t0;
+                    t0 = contribution - f_avg;
+                    t0 = t1 * t0;
+                    f_var = f_var + t0;
+                }
             }
-            if (act)
+            if (XYZ)
+            {
+                /* the pixel's tail wavelengths, summed over its R lanes by the group's first lane */
+                const double rw = spd_at(table, S, sp.cmf_rw, lam);
+                const double x = act ? (spd_at(table, S, sp.cmf_x, lam) * f_sum * rw) : 0.0;
+                const double y = act ? (spd_at(table, S, sp.cmf_y, lam) * f_sum * rw) : 0.0;
+                const double z = act ? (spd_at(table, S, sp.cmf_z, lam) * f_sum * rw) : 0.0;
+                double X = 0.0, Y = 0.0, Z = 0.0;
+                for (uint32_t t = 0; t < R; t += 1)
+                {
+                    const int src = (int)((lane - j + t) & 63u);
+                    X += __shfl(x, src);
+                    Y += __shfl(y, src);
+                    Z += __shfl(z, src);
+                }
+                if (act && j == 0)
+                {
+                    px[4] += X;
+                    px[5] += Y;
+                    px[6] += Z;
+                }
+            }
+            else if (act)
             {
                 px[lam] = f_sum;
                 pa[lam] = f_avg;
@@ -1451,6 +1518,21 @@ __global__ void drt_film_xyz_kernel(DevScene sc, uint32_t cmf_rw, uint32_t cmf_x
     xyz[3 * p + 0] = X * (interval / n);
     xyz[3 * p + 1] = Y * (interval / n);
     xyz[3 * p + 2] = Z * (interval / n);
+}
+
+/* XYZ film mode: accumulators -> per-pixel XYZ, the same normalisation as above (src/spectrum.c:52-69) */
+__global__ void drt_xyz_finish_kernel(DevScene sc, uint32_t cmf_rw, uint32_t cmf_y, double interval, uint64_t n_pix,
+                                      const double *__restrict__ film, double *__restrict__ xyz)
+{
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pix) return;
+    const uint32_t S = sc.S;
+    const double *rw = sc.spds + (size_t)cmf_rw * S, *cy = sc.spds + (size_t)cmf_y * S;
+    double n = 0.0;
+    for (uint32_t i = 0; i < S; i += 1) n += (cy[i] * rw[i]);
+    n *= interval;
+    const double *f = film + p * (uint64_t)XYZ_FILM_WORDS;
+    for (int c = 0; c < 3; c += 1) xyz[3 * p + c] = ((f[c] + f[4 + c]) / f[3]) * (interval / n);
 }
 
 /* arithmetic self-test (see drt_selftest_arith in include/drt_hip.h) */

@@ -50,7 +50,8 @@ struct drt_context
     double      interval = 0.0;
 
     std::vector<void *> allocations; /* scene tables */
-    double *d_pixels = nullptr, *d_avgs = nullptr, *d_vars = nullptr;
+    double *d_pixels = nullptr, *d_avgs = nullptr, *d_vars = nullptr; /* XYZ film mode: d_pixels is [n_pix][XYZ_FILM_WORDS], the others stay null */
+    bool    xyz_mode = false;
     bool    own_film = false;
     uint64_t *d_records = nullptr, *d_headers = nullptr;
     uint32_t  batch_spp = 1;
@@ -464,16 +465,22 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene)
     return 0;
 }
 
+template <int NSETS, bool XYZ>
+static int launch_shade_mode(drt_context *ctx, uint32_t grid, const ShadeParams &sp)
+{
+    if (ctx->spds_in_lds)
+        hipLaunchKernelGGL((drt_shade_kernel<NSETS, true, XYZ>), dim3(grid), dim3(SHADE_BLOCK), ctx->shade_lds, ctx->stream, ctx->dsc, sp,
+                           ctx->d_records, ctx->d_headers, ctx->d_pixels, ctx->d_avgs, ctx->d_vars, ctx->d_counters + DRT_NUM_COUNTERS + 1);
+    else
+        hipLaunchKernelGGL((drt_shade_kernel<NSETS, false, XYZ>), dim3(grid), dim3(SHADE_BLOCK), ctx->shade_lds, ctx->stream, ctx->dsc, sp,
+                           ctx->d_records, ctx->d_headers, ctx->d_pixels, ctx->d_avgs, ctx->d_vars, ctx->d_counters + DRT_NUM_COUNTERS + 1);
+    return 0;
+}
+
 template <int NSETS>
 static int launch_shade_sets(drt_context *ctx, uint32_t grid, const ShadeParams &sp)
 {
-    if (ctx->spds_in_lds)
-        hipLaunchKernelGGL((drt_shade_kernel<NSETS, true>), dim3(grid), dim3(SHADE_BLOCK), ctx->shade_lds, ctx->stream, ctx->dsc, sp,
-                           ctx->d_records, ctx->d_headers, ctx->d_pixels, ctx->d_avgs, ctx->d_vars, ctx->d_counters + DRT_NUM_COUNTERS + 1);
-    else
-        hipLaunchKernelGGL((drt_shade_kernel<NSETS, false>), dim3(grid), dim3(SHADE_BLOCK), ctx->shade_lds, ctx->stream, ctx->dsc, sp,
-                           ctx->d_records, ctx->d_headers, ctx->d_pixels, ctx->d_avgs, ctx->d_vars, ctx->d_counters + DRT_NUM_COUNTERS + 1);
-    return 0;
+    return ctx->xyz_mode ? launch_shade_mode<NSETS, true>(ctx, grid, sp) : launch_shade_mode<NSETS, false>(ctx, grid, sp);
 }
 
 /* How the S wavelengths map to lanes: n full 64-lane sets, plus (when the remainder is small) a packed tail pass */
@@ -503,14 +510,20 @@ static int launch_shade(drt_context *ctx, uint32_t grid, const ShadeParams &sp)
     }
 }
 
+template <int NSETS, bool XYZ>
+static int shade_occupancy_mode(drt_context *ctx, int *per_cu)
+{
+    if (ctx->spds_in_lds)
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, drt_shade_kernel<NSETS, true, XYZ>, SHADE_BLOCK, ctx->shade_lds));
+    else
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, drt_shade_kernel<NSETS, false, XYZ>, SHADE_BLOCK, ctx->shade_lds));
+    return 0;
+}
+
 template <int NSETS>
 static int shade_occupancy(drt_context *ctx, int *per_cu)
 {
-    if (ctx->spds_in_lds)
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, drt_shade_kernel<NSETS, true>, SHADE_BLOCK, ctx->shade_lds));
-    else
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, drt_shade_kernel<NSETS, false>, SHADE_BLOCK, ctx->shade_lds));
-    return 0;
+    return ctx->xyz_mode ? shade_occupancy_mode<NSETS, true>(ctx, per_cu) : shade_occupancy_mode<NSETS, false>(ctx, per_cu);
 }
 
 extern "C" const char *drt_last_error(void) { return g_last_error.c_str(); }
@@ -523,11 +536,18 @@ extern "C" int drt_device_count(void)
     return n;
 }
 
+/* bytes of the first film buffer: sum+filter rows, or the XYZ accumulators */
+static size_t pixels_bytes(const drt_context *ctx)
+{
+    return (size_t)ctx->n_pix * (ctx->xyz_mode ? (size_t)XYZ_FILM_WORDS : (size_t)ctx->dsc.S + 1) * 8;
+}
+
 static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camera *camera, const drt_params *params)
 {
     if (!scene || !camera || !params) return fail(-1, "null argument");
     if (params->tile_w == 0 || params->tile_h == 0 || params->max_depth == 0) return fail(-1, "empty tile or zero depth");
-    if (params->mode != DRT_MODE_SPECTRAL) return fail(-1, "only DRT_MODE_SPECTRAL (the reference's full spectral film) is implemented");
+    if (params->mode != DRT_MODE_SPECTRAL && params->mode != DRT_MODE_XYZ) return fail(-1, "unknown film mode %u", params->mode);
+    ctx->xyz_mode = params->mode == DRT_MODE_XYZ;
     if ((uint64_t)params->x0 + params->tile_w > params->width || (uint64_t)params->y0 + (uint64_t)(params->tile_h - 1) * (params->row_stride ? params->row_stride : 1) >= params->height)
         return fail(-1, "tile does not fit the %ux%u image", params->width, params->height);
     ctx->params = *params;
@@ -574,7 +594,7 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     batch = std::min<uint32_t>(batch, 4096);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    size_t film_bytes = (size_t)ctx->n_pix * (3 * (size_t)S + 1) * 8;
+    size_t film_bytes = ctx->xyz_mode ? (size_t)ctx->n_pix * XYZ_FILM_WORDS * 8 : (size_t)ctx->n_pix * (3 * (size_t)S + 1) * 8;
     while (batch > 1 && (size_t)ctx->n_pix * batch * ctx->path_words * 8 + film_bytes > free_b / 2) batch /= 2;
     ctx->batch_spp = batch;
     size_t rec_bytes = (size_t)ctx->n_pix * batch * ctx->path_words * 8;
@@ -582,13 +602,16 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     HIP_TRY(hipMalloc((void **)&ctx->d_records, rec_bytes));
     HIP_TRY(hipMalloc((void **)&ctx->d_headers, (size_t)ctx->n_pix * batch * REC_HEADER_WORDS * 8));
 
-    HIP_TRY(hipMalloc((void **)&ctx->d_pixels, (size_t)ctx->n_pix * (S + 1) * 8));
-    HIP_TRY(hipMalloc((void **)&ctx->d_avgs, (size_t)ctx->n_pix * S * 8));
-    HIP_TRY(hipMalloc((void **)&ctx->d_vars, (size_t)ctx->n_pix * S * 8));
+    HIP_TRY(hipMalloc((void **)&ctx->d_pixels, pixels_bytes(ctx)));
+    if (!ctx->xyz_mode)
+    {
+        HIP_TRY(hipMalloc((void **)&ctx->d_avgs, (size_t)ctx->n_pix * S * 8));
+        HIP_TRY(hipMalloc((void **)&ctx->d_vars, (size_t)ctx->n_pix * S * 8));
+    }
     ctx->own_film = true;
-    HIP_TRY(hipMemsetAsync(ctx->d_pixels, 0, (size_t)ctx->n_pix * (S + 1) * 8, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->d_avgs, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->d_vars, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_pixels, 0, pixels_bytes(ctx), ctx->stream));
+    if (ctx->d_avgs) HIP_TRY(hipMemsetAsync(ctx->d_avgs, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
+    if (ctx->d_vars) HIP_TRY(hipMemsetAsync(ctx->d_vars, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
     HIP_TRY(hipMalloc((void **)&ctx->d_counters, (DRT_NUM_COUNTERS + 2) * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 2) * sizeof(unsigned long long), ctx->stream));
 
@@ -677,7 +700,7 @@ extern "C" void drt_destroy(drt_context *ctx)
 
 extern "C" int drt_bind_film(drt_context *ctx, void *d_pixels, void *d_avgs, void *d_vars)
 {
-    if (!ctx || !d_pixels || !d_avgs || !d_vars) return fail(-1, "null argument");
+    if (!ctx || !d_pixels || (!ctx->xyz_mode && (!d_avgs || !d_vars))) return fail(-1, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->own_film)
@@ -809,6 +832,7 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
         sp.batch = ctx->batch_spp;
         sp.tail_first = ctx->tail_first;
         sp.tail_count = ctx->tail_count;
+        sp.cmf_rw = ctx->cmf_rw; sp.cmf_x = ctx->cmf_x; sp.cmf_y = ctx->cmf_y; sp.cmf_z = ctx->cmf_z;
         sp.chunk = ctx->tail_count ? 64u / ctx->tail_count : SHADE_PIXEL_CHUNK;
         uint64_t groups = (ctx->n_pix + sp.chunk - 1) / sp.chunk;
         /* work items: a group's main pass in pieces of sub_pixels pixels (+ its tail pass as an item of its own) when the
@@ -870,9 +894,9 @@ extern "C" int drt_reset_film(drt_context *ctx)
     int rc = drt_synchronize(ctx);
     if (rc) return rc;
     const size_t S = ctx->dsc.S;
-    HIP_TRY(hipMemsetAsync(ctx->d_pixels, 0, (size_t)ctx->n_pix * (S + 1) * 8, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->d_avgs, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->d_vars, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_pixels, 0, pixels_bytes(ctx), ctx->stream));
+    if (ctx->d_avgs) HIP_TRY(hipMemsetAsync(ctx->d_avgs, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
+    if (ctx->d_vars) HIP_TRY(hipMemsetAsync(ctx->d_vars, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 2) * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->trace_ms = ctx->shade_ms = 0.0;
@@ -894,7 +918,8 @@ extern "C" int drt_read_film(drt_context *ctx, double *pixels, double *avgs, dou
     int rc = drt_synchronize(ctx);
     if (rc) return rc;
     const size_t S = ctx->dsc.S;
-    if (pixels) HIP_TRY(hipMemcpy(pixels, ctx->d_pixels, (size_t)ctx->n_pix * (S + 1) * 8, hipMemcpyDeviceToHost));
+    if (ctx->xyz_mode && (avgs || vars)) return fail(-4, "the XYZ film has no mean / variance buffers");
+    if (pixels) HIP_TRY(hipMemcpy(pixels, ctx->d_pixels, pixels_bytes(ctx), hipMemcpyDeviceToHost));
     if (avgs) HIP_TRY(hipMemcpy(avgs, ctx->d_avgs, (size_t)ctx->n_pix * S * 8, hipMemcpyDeviceToHost));
     if (vars) HIP_TRY(hipMemcpy(vars, ctx->d_vars, (size_t)ctx->n_pix * S * 8, hipMemcpyDeviceToHost));
     return 0;
@@ -906,7 +931,8 @@ extern "C" int drt_write_film(drt_context *ctx, const double *pixels, const doub
     int rc = drt_synchronize(ctx);
     if (rc) return rc;
     const size_t S = ctx->dsc.S;
-    if (pixels) HIP_TRY(hipMemcpy(ctx->d_pixels, pixels, (size_t)ctx->n_pix * (S + 1) * 8, hipMemcpyHostToDevice));
+    if (ctx->xyz_mode && (avgs || vars)) return fail(-4, "the XYZ film has no mean / variance buffers");
+    if (pixels) HIP_TRY(hipMemcpy(ctx->d_pixels, pixels, pixels_bytes(ctx), hipMemcpyHostToDevice));
     if (avgs) HIP_TRY(hipMemcpy(ctx->d_avgs, avgs, (size_t)ctx->n_pix * S * 8, hipMemcpyHostToDevice));
     if (vars) HIP_TRY(hipMemcpy(ctx->d_vars, vars, (size_t)ctx->n_pix * S * 8, hipMemcpyHostToDevice));
     return 0;
@@ -918,8 +944,12 @@ extern "C" int drt_read_xyz(drt_context *ctx, double *xyz)
     HIP_TRY(hipSetDevice(ctx->device));
     if (!ctx->d_xyz) HIP_TRY(hipMalloc((void **)&ctx->d_xyz, (size_t)ctx->n_pix * 3 * 8));
     uint32_t grid = (uint32_t)((ctx->n_pix + 255) / 256);
-    hipLaunchKernelGGL(drt_film_xyz_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->dsc, ctx->cmf_rw, ctx->cmf_x, ctx->cmf_y,
-                       ctx->cmf_z, ctx->interval, ctx->n_pix, ctx->d_pixels, ctx->d_xyz);
+    if (ctx->xyz_mode)
+        hipLaunchKernelGGL(drt_xyz_finish_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->dsc, ctx->cmf_rw, ctx->cmf_y, ctx->interval,
+                           ctx->n_pix, ctx->d_pixels, ctx->d_xyz);
+    else
+        hipLaunchKernelGGL(drt_film_xyz_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->dsc, ctx->cmf_rw, ctx->cmf_x, ctx->cmf_y,
+                           ctx->cmf_z, ctx->interval, ctx->n_pix, ctx->d_pixels, ctx->d_xyz);
     HIP_TRY(hipGetLastError());
     int rc = drt_synchronize(ctx);
     if (rc) return rc;
@@ -969,7 +999,9 @@ extern "C" int drt_render_tile(const drt_scene *scene, const drt_camera *camera,
                                double *dst_pixels, double *dst_avgs, double *dst_vars, drt_stats *stats)
 {
     g_last_error.clear();
-    if (!dst_pixels || !dst_avgs || !dst_vars) return fail(-1, "null film buffer");
+    const bool xyz = params && params->mode == DRT_MODE_XYZ; /* then dst_pixels is [n][8] and the other two are not used */
+    if (!dst_pixels || (!xyz && (!dst_avgs || !dst_vars))) return fail(-1, "null film buffer");
+    if (xyz) dst_avgs = dst_vars = nullptr;
     const bool verbose = getenv("DRT_VERBOSE") != nullptr || getenv("DRT_TIMING") != nullptr;
     double t[6] = {wall_ms(), 0, 0, 0, 0, 0};
     drt_context *ctx = drt_create(scene, camera, params);
@@ -1006,6 +1038,7 @@ struct drt_group
     std::vector<drt_context *> ctx; /* nullptr for a device that got no rows */
     std::vector<uint32_t>      rows;
     uint32_t tile_w = 0, tile_h = 0, S = 0;
+    bool     xyz_mode = false;
 };
 
 extern "C" void drt_group_destroy(drt_group *g)
@@ -1052,6 +1085,7 @@ extern "C" drt_group *drt_group_create(const drt_scene *scene, const drt_camera 
     g->tile_w = params->tile_w;
     g->tile_h = params->tile_h;
     g->S = scene->num_wavelengths;
+    g->xyz_mode = params->mode == DRT_MODE_XYZ;
     for (uint32_t k = 0; k < n_devices; k += 1)
     {
         drt_params p = *params;
@@ -1107,7 +1141,8 @@ static int group_copy(drt_group *g, double *host, int which, bool to_device)
 {
     if (!host) return 0;
     const size_t n = g->ctx.size();
-    const size_t C = which == 0 ? (size_t)g->S + 1 : (size_t)g->S;
+    const size_t C = which == 0 ? (g->xyz_mode ? (size_t)XYZ_FILM_WORDS : (size_t)g->S + 1) : (size_t)g->S;
+    if (g->xyz_mode && which != 0) return fail(-4, "the XYZ film has no mean / variance buffers");
     const size_t row_bytes = (size_t)g->tile_w * C * 8;
     for (size_t k = 0; k < n; k += 1)
     {
@@ -1169,7 +1204,9 @@ extern "C" int drt_render_tile_multi(const drt_scene *scene, const drt_camera *c
                                      double *dst_vars, drt_stats *stats)
 {
     g_last_error.clear();
-    if (!dst_pixels || !dst_avgs || !dst_vars) return fail(-1, "null film buffer");
+    const bool xyz = params && params->mode == DRT_MODE_XYZ;
+    if (!dst_pixels || (!xyz && (!dst_avgs || !dst_vars))) return fail(-1, "null film buffer");
+    if (xyz) dst_avgs = dst_vars = nullptr;
     drt_group *g = drt_group_create(scene, camera, params, devices, n_devices);
     if (!g) return -1;
     int rc = 0;

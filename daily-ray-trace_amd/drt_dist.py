@@ -66,15 +66,16 @@ class FilmGather:
     A block covers the row indices j in [j0, j0 + block_rows) on every rank (fewer on ranks that run out of rows).
     Rendering block b+1 while block b's gather is in flight (gather_async) hides the transfer behind compute."""
 
-    def __init__(self, height, width, S, rank, world, device, dst=0, j0=0, block_rows=None, image=None):
+    def __init__(self, height, width, S, rank, world, device, dst=0, j0=0, block_rows=None, image=None, channels=None):
         self.height, self.width, self.S, self.rank, self.world, self.dst = height, width, S, rank, world, dst
         self.j0 = j0
         self.block_rows = max_tile_rows(height, world) if block_rows is None else block_rows
         self.rows = self.rows_of(rank)
-        self.channels = (S + 1, S, S)
+        # doubles per pixel of each film buffer: the spectral film's three, or (8,) for the XYZ film (DRT_MODE_XYZ)
+        self.channels = tuple(channels) if channels else (S + 1, S, S)
         n_max = self.block_rows * width
-        self.offsets = [0, n_max * (S + 1), n_max * (2 * S + 1)]
-        self.flat = torch.zeros(n_max * (3 * S + 1), dtype=torch.float64, device=device)
+        self.offsets = [n_max * sum(self.channels[:i]) for i in range(len(self.channels))]
+        self.flat = torch.zeros(n_max * sum(self.channels), dtype=torch.float64, device=device)
         self.recv = torch.empty((world, self.flat.numel()), dtype=torch.float64, device=device) if (rank == dst and world > 1) else None
         if rank == dst:
             self.image = image if image is not None else [torch.empty((height, width, c), dtype=torch.float64, device=device) for c in self.channels]
@@ -115,7 +116,7 @@ class FilmGather:
     def finish(self):
         """Wait for the gather, then (dst only) de-interleave the block's rows into the frame. Returns the frame buffers on dst."""
         if self.world == 1:
-            for i in range(3):
+            for i in range(len(self.channels)):
                 self.image[i][self.j0: self.j0 + self.rows] = self.region(i).view(self.rows, self.width, self.channels[i])
             return self.image
         if self._work is not None:
@@ -143,7 +144,7 @@ class FilmGather:
         return self.finish()
 
 
-def film_blocks(height, width, S, rank, world, device, n_blocks, dst=0):
+def film_blocks(height, width, S, rank, world, device, n_blocks, dst=0, channels=None):
     """Split every rank's rows into n_blocks row blocks sharing one frame on dst: [FilmGather, ...]."""
     rows_max = max_tile_rows(height, world)
     per = (rows_max + n_blocks - 1) // n_blocks
@@ -151,7 +152,7 @@ def film_blocks(height, width, S, rank, world, device, n_blocks, dst=0):
     for b in range(n_blocks):
         if b * per >= rows_max:
             break
-        fg = FilmGather(height, width, S, rank, world, device, dst=dst, j0=b * per, block_rows=min(per, rows_max - b * per), image=image)
+        fg = FilmGather(height, width, S, rank, world, device, dst=dst, j0=b * per, block_rows=min(per, rows_max - b * per), image=image, channels=channels)
         image = fg.image
         blocks.append(fg)
     return blocks

@@ -384,6 +384,16 @@ class Renderer:
         _check(self.L.drt_film_device_ptrs(self.ctx, C.byref(a), C.byref(b), C.byref(c)), "drt_film_device_ptrs")
         return a.value, b.value, c.value
 
+    def read_xyz_film(self):
+        """XYZ film mode: the raw [n][8] accumulators (X, Y, Z, filter sum, tail X, Y, Z, 0)."""
+        acc = np.empty((self.n_pixels, 8), dtype=np.float64)
+        _check(self.L.drt_read_film(self.ctx, _ptr(acc, C.c_double), None, None), "drt_read_film")
+        return acc
+
+    def write_xyz_film(self, acc):
+        acc = np.ascontiguousarray(acc, dtype=np.float64)
+        _check(self.L.drt_write_film(self.ctx, _ptr(acc, C.c_double), None, None), "drt_write_film")
+
     def read_film(self):
         px = np.empty((self.n_pixels, self.S + 1), dtype=np.float64)
         av = np.empty((self.n_pixels, self.S), dtype=np.float64)

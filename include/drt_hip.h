@@ -141,7 +141,12 @@ typedef struct drt_camera
 enum
 {
     DRT_MODE_SPECTRAL = 0, /* film = sum(+filter), mean, variance per wavelength (the reference's output) */
-    DRT_MODE_XYZ      = 1  /* reserved: XYZ-only film (not implemented; drt_create rejects it) */
+    DRT_MODE_XYZ      = 1  /* XYZ-only film ("a different mode", reported as such): per pixel 8 doubles
+                              {X, Y, Z numerators of wavelengths 0..63.., filter sum, X, Y, Z of the tail wavelengths, 0};
+                              spectrum_to_xyz's sums are taken per kernel pair and added up, so no spectrum is kept, there
+                              is no mean / variance, and 64 instead of 1664 bytes per pixel cross the links. In this mode
+                              the "pixels" buffer of every call below is [tile_h*tile_w][8] and avgs / vars are NULL;
+                              drt_read_xyz() gives the same XYZ as the spectral film's to rounding (order of sums). */
 };
 
 /*

@@ -64,6 +64,18 @@ def _worker(rank, world, port, height, width, out_path):
     if rank == 0:
         for a, b in zip(full, piped):
             assert torch.equal(a, b)
+    # one buffer of 8 doubles per pixel (the XYZ film's layout) through the same blocks
+    blocks8 = drt_dist.film_blocks(height, width, S, rank, world, torch.device("cpu"), 2, channels=(8,))
+    for fb in blocks8:
+        by0, brows, bstride = fb.tile()
+        if brows:
+            fb.region(0).copy_(render_tile(by0, brows, bstride)[0][:, :8])
+        fb.gather_async()
+    img8 = None
+    for fb in blocks8:
+        img8 = fb.finish()
+    if rank == 0:
+        assert len(img8) == 1 and torch.equal(img8[0], full[0][:, :, :8])
     dist.barrier()
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the max-over-ranks timing reduction bench.py uses

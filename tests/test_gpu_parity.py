@@ -192,6 +192,61 @@ def test_device_group_gives_the_single_context_film():
         pydrt.Group(bundle, params, [0, 99])
 
 
+@pytest.mark.parametrize("name", ["plane_light_48", "gold_mirror", "many_lights", "grid_2p5nm", "grid_4nm", "grid_10nm"])
+def test_xyz_film_mode_matches_the_spectral_film(name):
+    """DRT_MODE_XYZ keeps 8 accumulators per pixel instead of three spectra: its XYZ equals the spectral film's XYZ (and the
+    oracle's) to rounding -- the sums are the same terms in another order -- whatever the batch size, and the film can be read,
+    written back and continued; there is no mean / variance to ask for."""
+    bundle, params = cases.load_case(name)
+    spectral = hip_render(bundle, params, record_hits=False)
+    acc0 = None
+    oxyz = O.oracle_film_to_xyz(bundle, O.oracle_render_tile(bundle, params, math_mode=O.MATH_DEVICE)[0])
+    spp = int(params.spp)
+    for batch in (0, 1, 3):
+        p = pydrt.make_params(int(params.width), int(params.height), spp=spp, max_depth=int(params.max_depth), seed=int(params.seed),
+                              pixel_scheme=int(params.pixel_scheme), mode=pydrt.MODE_XYZ, batch_spp=batch)
+        r = pydrt.Renderer(bundle, p)
+        r.render()
+        xyz = r.read_xyz()
+        acc = r.read_xyz_film()
+        st = r.stats()
+        assert cases.xyz_rel_err(xyz, spectral[4]) <= 1e-12 and cases.xyz_rel_err(xyz, oxyz) <= XYZ_TOL
+        assert np.all(acc[:, 3] == float(spp)) and np.all(acc[:, 7] == 0.0)
+        assert (st.paths, st.rng_draws) == (spectral[5].paths, spectral[5].rng_draws)
+        with pytest.raises(RuntimeError):
+            r.read_film()
+        r.close()
+        if batch == 0:
+            acc0 = acc
+    # stop after the first sample, carry the accumulators over to a new context, continue
+    if spp >= 2:
+        p = pydrt.make_params(int(params.width), int(params.height), spp=spp, max_depth=int(params.max_depth), seed=int(params.seed),
+                              pixel_scheme=int(params.pixel_scheme), mode=pydrt.MODE_XYZ)
+        r = pydrt.Renderer(bundle, p)
+        r.render(0, 1)
+        half = r.read_xyz_film()
+        r.close()
+        r = pydrt.Renderer(bundle, p)
+        r.write_xyz_film(half)
+        r.render(1, spp - 1)
+        assert cases.xyz_rel_err(r.read_xyz(), spectral[4]) <= 1e-12
+        r.close()
+    # one-shot forms and a device group in XYZ mode
+    p = pydrt.make_params(int(params.width), int(params.height), spp=spp, max_depth=int(params.max_depth), seed=int(params.seed),
+                          pixel_scheme=int(params.pixel_scheme), mode=pydrt.MODE_XYZ)
+    L = pydrt.hip_lib()
+    f64p = C.POINTER(C.c_double)
+    n = int(params.width) * int(params.height)
+    acc = np.zeros((n, 8))
+    rc = L.drt_render_tile(C.byref(bundle.scene), C.byref(bundle.camera), C.byref(p), acc.ctypes.data_as(f64p), None, None, None)
+    assert rc == 0, L.drt_last_error()
+    acc3 = np.zeros((n, 8))
+    devs = (C.c_int32 * 3)(0, 0, 0)
+    rc = L.drt_render_tile_multi(C.byref(bundle.scene), C.byref(bundle.camera), C.byref(p), devs, 3, acc3.ctypes.data_as(f64p), None, None, None)
+    assert rc == 0, L.drt_last_error()
+    assert np.array_equal(acc, acc3) and np.array_equal(acc, acc0)  # same launches, same order of sums: the same bits
+
+
 def test_one_shot_render_tile_accumulates_into_host_buffers():
     bundle, params = cases.load_case("plane_light_16")
     px, av, va, st = pydrt.render_tile(bundle, params)
