@@ -107,21 +107,54 @@ struct BuildPrim
     uint32_t idx;
 };
 
+/* Box of everything a surface's intersector can report a hit on. A plane accepts the points j (relative to its
+ * `position`) of the plane through it with 0 <= j.u^ <= |u| and 0 <= j.v^ <= |v| (src/geometry.c:157-182): the rectangle
+ * position + a u + b v only when u and v are perpendicular; for slanted edge vectors it is the parallelogram whose
+ * corners solve [u^; v^; n] j = (a, b, 0) at the four (a, b) extremes -- bounded here by solving exactly that. */
 static void prim_bounds(const drt_surface &s, double lo[3], double hi[3])
 {
-    for (int k = 0; k < 3; k += 1)
+    if (s.type == DRT_GEO_SPHERE)
     {
-        if (s.type == DRT_GEO_SPHERE)
+        for (int k = 0; k < 3; k += 1)
         {
             lo[k] = s.position[k] - std::fabs(s.radius);
             hi[k] = s.position[k] + std::fabs(s.radius);
         }
-        else
+    }
+    else
+    {
+        const double ul = h_length(s.u), vl = h_length(s.v);
+        const double un[3] = {s.u[0] / ul, s.u[1] / ul, s.u[2] / ul}, vn[3] = {s.v[0] / vl, s.v[1] / vl, s.v[2] / vl};
+        const double *n = s.normal;
+        /* rows of M = u^, v^, n; its inverse by cofactors */
+        const double c0[3] = {vn[1] * n[2] - vn[2] * n[1], vn[2] * n[0] - vn[0] * n[2], vn[0] * n[1] - vn[1] * n[0]}; /* v^ x n */
+        const double c1[3] = {n[1] * un[2] - n[2] * un[1], n[2] * un[0] - n[0] * un[2], n[0] * un[1] - n[1] * un[0]}; /* n x u^ */
+        const double det = un[0] * c0[0] + un[1] * c0[1] + un[2] * c0[2];
+        const bool ok = std::isfinite(det) && std::fabs(det) > 1e-6 && std::isfinite(ul) && std::isfinite(vl);
+        for (int k = 0; k < 3; k += 1)
         {
-            double c0 = s.position[k], c1 = c0 + s.u[k], c2 = c0 + s.v[k], c3 = c0 + s.u[k] + s.v[k];
-            lo[k] = std::min(std::min(c0, c1), std::min(c2, c3));
-            hi[k] = std::max(std::max(c0, c1), std::max(c2, c3));
+            lo[k] = HUGE_VAL;
+            hi[k] = -HUGE_VAL;
         }
+        for (int corner = 0; corner < 4 && ok; corner += 1)
+        {
+            const double a = (corner & 1) ? ul : 0.0, b = (corner & 2) ? vl : 0.0;
+            for (int k = 0; k < 3; k += 1)
+            {
+                double j = (a * c0[k] + b * c1[k]) / det; /* M^-1 (a, b, 0) */
+                lo[k] = std::min(lo[k], s.position[k] + j);
+                hi[k] = std::max(hi[k], s.position[k] + j);
+            }
+        }
+        if (!ok) /* edge vectors (nearly) parallel, or a normal in their span: the accepted region is unbounded */
+            for (int k = 0; k < 3; k += 1)
+            {
+                lo[k] = -1e300;
+                hi[k] = 1e300;
+            }
+    }
+    for (int k = 0; k < 3; k += 1)
+    {
         /* pad: a hit the intersector COMPUTES (rounding included) must stay inside the box */
         double pad = 1e-5 + 1e-9 * std::max(std::fabs(lo[k]), std::fabs(hi[k]));
         lo[k] -= pad;

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import cases
+import fuzz_scenes
 import oracle_py as O
 import pydrt
 
@@ -82,6 +83,19 @@ def test_hip_matches_oracle_and_golden(name, golden_dir):
         assert np.array_equal(hits, g["hits"])  # bit-exact hit-primitive indices against the reference
     for got, key in ((px[:, :S].sum(axis=1), "pix_sum"), (av.sum(axis=1), "avg_sum"), (va.sum(axis=1), "var_sum")):
         assert cases.rel_err(got, g[key]) <= 1e-11
+
+
+@pytest.mark.parametrize("seed", fuzz_scenes.FUZZ_SEEDS)
+def test_random_scenes_match_the_oracle(seed):
+    """Random scenes (tests/fuzz_scenes.py): hit indices, statistics and RNG draws exact, film within 1e-12, NaN for NaN
+    (total internal reflection propagates NaN through a path in the reference, src/geometry.c:92-106)."""
+    bundle, params = fuzz_scenes.load(seed, pydrt)
+    px, av, va, hits, xyz, st = hip_render(bundle, params)
+    opx, oav, ova, ohits, ost = O.oracle_render_tile(bundle, params, want_hits=True, math_mode=O.MATH_DEVICE)
+    assert np.array_equal(hits, ohits), "%d closest-hit indices differ" % int((hits != ohits).sum())
+    assert (st.paths, st.closest_hit_scans, st.shaded_vertices, st.shadow_scans, st.rng_draws) == \
+           (ost.paths, ost.closest_hit_scans, ost.shaded_vertices, ost.shadow_scans, ost.rng_draws)
+    assert fuzz_scenes.same(px, opx, FILM_TOL) and fuzz_scenes.same(av, oav, FILM_TOL) and fuzz_scenes.same(va, ova, FILM_TOL)
 
 
 def test_batching_resume_and_tiles_do_not_change_a_bit():
