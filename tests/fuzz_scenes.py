@@ -88,8 +88,10 @@ FUZZ_SEEDS = list(range(1, 49)) + list(range(100, 108))
 FUZZ_SIZE, FUZZ_SPP, FUZZ_DEPTH = 12, 3, 6
 
 
-def load(seed, pydrt):
-    bundle = pydrt.load_scene_text(random_scene_text(seed), FUZZ_SIZE, FUZZ_SIZE)
+def load(seed, pydrt, grid=None):
+    """grid: (min_wl, max_wl, interval) or None for the reference's 380..720 step 5"""
+    kw = dict(min_wl=grid[0], max_wl=grid[1], wl_interval=grid[2]) if grid else {}
+    bundle = pydrt.load_scene_text(random_scene_text(seed), FUZZ_SIZE, FUZZ_SIZE, **kw)
     params = pydrt.make_params(FUZZ_SIZE, FUZZ_SIZE, spp=FUZZ_SPP, max_depth=FUZZ_DEPTH, seed=1000 + seed)
     return bundle, params
 
@@ -106,3 +108,11 @@ def same(a, b, tol=0.0):
         return bool(np.array_equal(a[fa], b[fb]))
     scale = float(np.max(np.abs(b[fb]))) if fb.any() else 1.0
     return bool(np.max(np.abs(a[fa] - b[fb]), initial=0.0) <= tol * (scale if scale > 0 else 1.0))
+
+
+# wavelength grids by sample count S: lane sets x tail widths of the shade kernel (S = 64k + r: r <= 16 is a packed tail)
+# (every grid brackets 630 nm, which the dielectric sampler looks up: the reference reads past the array otherwise and
+# drt_create refuses such a grid)
+FUZZ_GRIDS = {S: (400.0, 400.0 + (S - 1) * step, step) for S, step in
+              ((2, 250.0), (5, 60.0), (63, 5.0), (64, 5.0), (65, 5.0), (70, 4.0), (80, 4.0), (81, 4.0), (128, 2.0), (129, 2.0),
+               (144, 2.0), (145, 2.0), (192, 1.5), (200, 1.5), (256, 1.0))}

@@ -98,6 +98,29 @@ def test_random_scenes_match_the_oracle(seed):
     assert fuzz_scenes.same(px, opx, FILM_TOL) and fuzz_scenes.same(av, oav, FILM_TOL) and fuzz_scenes.same(va, ova, FILM_TOL)
 
 
+@pytest.mark.parametrize("S", list(fuzz_scenes.FUZZ_GRIDS))
+def test_random_scenes_on_other_wavelength_grids(S):
+    """Random scenes on grids from 2 to 256 wavelengths: every lane-set count of the shade kernel (1-4), tails of 1, 6, 16
+    wavelengths (packed pass) and 17 (a further set instead), in spectral and XYZ film mode."""
+    grid = fuzz_scenes.FUZZ_GRIDS[S]
+    for seed in (3 + S % 7, 101):
+        bundle, params = fuzz_scenes.load(seed, pydrt, grid)
+        assert bundle.S == S
+        px, av, va, hits, xyz, st = hip_render(bundle, params)
+        opx, oav, ova, ohits, ost = O.oracle_render_tile(bundle, params, want_hits=True, math_mode=O.MATH_DEVICE)
+        assert np.array_equal(hits, ohits) and st.rng_draws == ost.rng_draws
+        assert fuzz_scenes.same(px, opx, FILM_TOL) and fuzz_scenes.same(av, oav, FILM_TOL) and fuzz_scenes.same(va, ova, FILM_TOL)
+        p = pydrt.make_params(int(params.width), int(params.height), spp=int(params.spp), max_depth=int(params.max_depth),
+                              seed=int(params.seed), mode=pydrt.MODE_XYZ)
+        r = pydrt.Renderer(bundle, p)
+        r.render()
+        xyz2 = r.read_xyz()
+        r.close()
+        ok = np.isfinite(xyz).all(axis=1)
+        assert np.array_equal(ok, np.isfinite(xyz2).all(axis=1))
+        assert cases.xyz_rel_err(xyz2[ok], xyz[ok]) <= 1e-11
+
+
 def test_batching_resume_and_tiles_do_not_change_a_bit():
     bundle, params = cases.load_case("plane_light_48")
     base = hip_render(bundle, params, batch=4)
@@ -303,6 +326,13 @@ def test_errors_are_reported_not_swallowed():
     with pytest.raises(RuntimeError):
         r.read_hit_indices(4)
     r.close()
+    # a grid that does not reach the 630 nm the dielectric sampler looks up (the reference reads past its arrays there)
+    short = pydrt.load_scene(cases.scene_path("cornell_plane_light.scn"), 16, 16, min_wl=400.0, max_wl=550.0, wl_interval=150.0)
+    assert not L.drt_create(C.byref(short.scene), C.byref(short.camera), C.byref(params))
+    assert b"630" in L.drt_last_error()
+    unknown_mode = pydrt.make_params(16, 16, spp=1, max_depth=2, mode=7)
+    assert not L.drt_create(C.byref(bundle.scene), C.byref(bundle.camera), C.byref(unknown_mode))
+    assert b"mode" in L.drt_last_error()
 
 
 def test_large_scene_outside_lds():

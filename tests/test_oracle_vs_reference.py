@@ -68,3 +68,14 @@ def test_random_scenes_bit_identical(seed):
     if bundle.camera.aperture_radius == 0.0:  # the harness's hit log replays pinhole paths only (oracle/ref_harness.c)
         hits, replay, real = O.ref_trace_hits(bundle, params)
         assert fuzz_scenes.same(replay, real) and np.array_equal(hits, ohits)
+
+
+@pytest.mark.parametrize("S", list(fuzz_scenes.FUZZ_GRIDS))
+def test_random_scenes_on_other_wavelength_grids_bit_identical(S):
+    """The same comparison on grids from 2 to 256 wavelengths (incl. grids that end below the 630 nm the dielectric
+    sampler looks up, src/daily_ray_trace.c:381)."""
+    bundle, params = fuzz_scenes.load(3 + S % 7, pydrt, fuzz_scenes.FUZZ_GRIDS[S])
+    assert bundle.S == S
+    rp, ra, rv = O.ref_render_tile(bundle, params)
+    op, oa, ov, _, _ = O.oracle_render_tile(bundle, params, math_mode=O.MATH_REFERENCE)
+    assert fuzz_scenes.same(op, rp) and fuzz_scenes.same(oa, ra) and fuzz_scenes.same(ov, rv)
