@@ -121,6 +121,39 @@ def test_random_scenes_on_other_wavelength_grids(S):
         assert cases.xyz_rel_err(xyz2[ok], xyz[ok]) <= 1e-11
 
 
+@pytest.mark.parametrize("trial", range(16))
+def test_random_tiles_batches_and_sample_splits(trial):
+    """Random image shapes (not square), tile rectangles, row strides, depths, pixel schemes, batch sizes and splits of the
+    samples over several drt_render calls, on random scenes: always the oracle's film for exactly that tile."""
+    r = np.random.default_rng(7000 + trial)
+    w, h = int(r.integers(5, 40)), int(r.integers(5, 40))
+    stride = int(r.integers(1, 4))
+    tile_w = int(r.integers(1, w + 1)); x0 = int(r.integers(0, w - tile_w + 1))
+    y0 = int(r.integers(0, h))
+    tile_h = int(r.integers(1, (h - 1 - y0) // stride + 2))
+    spp, first = int(r.integers(1, 9)), int(r.integers(0, 5))
+    depth = int(r.choice([1, 2, 3, 8, 17]))
+    scheme = int(r.choice([pydrt.FILM_SAMPLE_RANDOM, pydrt.FILM_SAMPLE_CENTER]))
+    seed = int(r.integers(1, 2 ** 40))
+    text = fuzz_scenes.random_scene_text(int(r.choice([4, 9, 16, 23, 103])))
+    bundle = pydrt.load_scene_text(text, w, h)
+    base = dict(spp=spp, max_depth=depth, seed=seed, x0=x0, y0=y0, tile_w=tile_w, tile_h=tile_h, row_stride=stride,
+                first_sample=first, pixel_scheme=scheme)
+    p = pydrt.make_params(w, h, batch_spp=int(r.integers(0, 6)), **base)
+    ren = pydrt.Renderer(bundle, p)
+    done = 0
+    while done < spp:  # the samples in random pieces
+        n = int(r.integers(1, spp - done + 1))
+        ren.render(first + done, n)
+        done += n
+    px, av, va = ren.read_film()
+    st = ren.stats()
+    ren.close()
+    opx, oav, ova, _, ost = O.oracle_render_tile(bundle, pydrt.make_params(w, h, **base), math_mode=O.MATH_DEVICE)
+    assert (st.paths, st.closest_hit_scans, st.rng_draws) == (ost.paths, ost.closest_hit_scans, ost.rng_draws)
+    assert fuzz_scenes.same(px, opx, FILM_TOL) and fuzz_scenes.same(av, oav, FILM_TOL) and fuzz_scenes.same(va, ova, FILM_TOL)
+
+
 def test_batching_resume_and_tiles_do_not_change_a_bit():
     bundle, params = cases.load_case("plane_light_48")
     base = hip_render(bundle, params, batch=4)
