@@ -79,3 +79,52 @@ def test_random_scenes_on_other_wavelength_grids_bit_identical(S):
     rp, ra, rv = O.ref_render_tile(bundle, params)
     op, oa, ov, _, _ = O.oracle_render_tile(bundle, params, math_mode=O.MATH_REFERENCE)
     assert fuzz_scenes.same(op, rp) and fuzz_scenes.same(oa, ra) and fuzz_scenes.same(ov, rv)
+
+
+def test_host_scene_build_pieces_on_random_inputs():
+    """The product's host code (host/drt_scene.c, host/drt_spectrum.c) against the reference's own init_camera,
+    rgb_f64_to_spectrum, generate_blackbody_spectrum and spectrum_to_rgb on random inputs, on the reference grid and on a
+    10 nm one. rgb -> spectrum is bit for bit; the camera and the black body go through tan / expl / powl and are held to 1e-13."""
+    import ctypes as C
+    H, R = pydrt.host_lib(), O.ref_lib()
+    f64p = C.POINTER(C.c_double)
+    p = lambda a: a.ctypes.data_as(f64p)
+    H.drt_host_spectrum_to_rgb.argtypes = [f64p, C.c_uint32, C.c_double, f64p, f64p]
+    r = np.random.default_rng(99)
+    for wl_interval in (5.0, 10.0):
+        bundle = pydrt.load_scene(cases.scene_path("cornell_plane_light.scn"), 32, 32, wl_interval=wl_interval)
+        S = bundle.S
+        sc = bundle.scene
+        block = np.ctypeslib.as_array(sc.spds, shape=(sc.num_spds, S))
+        tables = np.ascontiguousarray(np.stack([block[sc.cmf_rw], block[sc.cmf_x], block[sc.cmf_y], block[sc.cmf_z]] +
+                                               [block[sc.cmf_z + 1 + k] for k in range(7)]))  # host/drt_scene.c: 11 adjacent rows
+        R.ref_set_grid(S, 380.0, wl_interval)
+        R.ref_set_tables(p(tables))
+        rgb_tables = np.ascontiguousarray(tables[4:11])
+        a, b = np.zeros(S), np.zeros(S)
+        for _ in range(200):
+            rgb = r.uniform(0.0, 1.2, 3)
+            if r.random() < 0.3:
+                rgb[int(r.integers(0, 3))] = rgb[int(r.integers(0, 3))]  # ties between channels pick the branches' edges
+            H.drt_host_rgb_to_spectrum(p(rgb_tables), S, p(rgb.copy()), p(a))
+            R.ref_rgb_to_spectrum(p(rgb.copy()), p(b))
+            assert np.array_equal(a, b)
+            t = float(r.uniform(800.0, 12000.0))
+            H.drt_host_blackbody_spectrum(380.0, wl_interval, S, t, p(a))
+            R.ref_blackbody(t, p(b))
+            np.testing.assert_allclose(a, b, rtol=1e-13)
+            spd = r.uniform(0.0, 3.0, S)
+            rgb_h, rgb_r = np.zeros(3), np.zeros(3)
+            H.drt_host_spectrum_to_rgb(p(np.ascontiguousarray(tables[0:4])), S, wl_interval, p(spd), p(rgb_h))
+            R.ref_spectrum_to_rgb(p(spd.copy()), p(rgb_r))
+            assert np.array_equal(rgb_h, rgb_r)
+    for _ in range(300):
+        pos = r.uniform(-10, 10, 3); tgt = r.uniform(-10, 10, 3)
+        roll, fov = float(r.uniform(-180, 180)), float(r.uniform(10, 140))
+        fdepth, flength, aperture = float(r.uniform(0.5, 20)), float(r.uniform(0.05, 2)), float(r.choice([0.0, r.uniform(0.01, 0.5)]))
+        w, h = int(r.integers(1, 3000)), int(r.integers(1, 3000))
+        cam_h = pydrt.init_camera(pos, tgt, roll, fov, fdepth, flength, aperture, w, h)
+        cam_r = pydrt.Camera()
+        R.ref_init_camera(C.byref(cam_r), p(pos.copy()), p(tgt.copy()), roll, fov, fdepth, flength, aperture, w, h)
+        np.testing.assert_allclose(np.frombuffer(bytes(cam_h), dtype=np.float64), np.frombuffer(bytes(cam_r), dtype=np.float64),
+                                   rtol=1e-13, atol=1e-13)
