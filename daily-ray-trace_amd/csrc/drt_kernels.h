@@ -988,8 +988,12 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
  * into LDS once) and draw work items (pixel groups, or pieces of them: see the queue below) from a global counter,
  * because pixel cost varies.
  */
+#ifndef SHADE_PREFETCH_REGS
 #define SHADE_PREFETCH_REGS 2 /* 64-word registers per path: 128 record words are prefetched, deeper paths fall back */
-#define SHADE_PREFETCH_DEPTH 3 /* samples whose record loads are in flight ahead of the one being replayed */
+#endif
+#ifndef SHADE_PREFETCH_DEPTH
+#define SHADE_PREFETCH_DEPTH 2 /* samples whose record loads are in flight ahead of the one being replayed */
+#endif
 #define SHADE_PIXEL_CHUNK 16 /* pixels per group when there is no tail pass (with one: 64 / tail wavelengths) */
 
 #define XYZ_FILM_WORDS 8 /* XYZ film mode, per pixel: X, Y, Z numerators of the main pass, filter sum, X, Y, Z of the tail pass, unused */
@@ -1152,7 +1156,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
                 {
                     const uint32_t sel = v / vpr;
                     lane0 = (v - sel * vpr) * vw;
-                    src = sel == 0 ? cur[0] : cur[1];
+                    src = cur[0];
+                    if (SHADE_PREFETCH_REGS > 1 && sel != 0) src = cur[SHADE_PREFETCH_REGS > 1 ? 1 : 0];
                 }
                 else
                 {
