@@ -128,7 +128,9 @@ def main():
     # The rank's rows (cyclic over the ranks) in row blocks: each block is one contiguous film buffer (three regions)
     # with its own render context; block b's gather to rank 0 is in flight while block b+1 renders.
     # Blocks of >= 128k pixels keep the kernels' last rounds short; at least 2 so a gather can hide.
-    n_blocks = args.gather_blocks if args.gather_blocks > 0 else (max(2, min(8, n_tile // (128 * 1024))) if world > 1 else 1)
+    # (from the LARGEST tile, so that every rank arrives at the same number of blocks = the same sequence of collectives)
+    max_tile = drt_dist.max_tile_rows(H, world) * W
+    n_blocks = args.gather_blocks if args.gather_blocks > 0 else (max(2, min(8, max_tile // (128 * 1024))) if world > 1 else 1)
     xyz = args.film == "xyz"
     blocks = drt_dist.film_blocks(H, W, S, rank, world, dev, n_blocks, channels=(8,) if xyz else None)
     # One explicit (non-default) stream carries the film zero-fill, the kernels, the collectives' dependencies and the
