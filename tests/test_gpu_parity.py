@@ -524,6 +524,12 @@ def test_bench_two_rank_rehearsal_assembles_the_same_frame():
                      "--master-port", "29533", bench, "--gpus", "2", "--backend", "gloo", "--share-device", "--gather-blocks", "3"] + common)
     assert two["n_gpus"] == 2 and two["frame_checksum"] == one["frame_checksum"]
     assert two["config"]["paths_per_step"] == 96 * 96 * 6
+    # three ranks on an image whose rows do not divide evenly (ranks own 34, 33, 33 rows of 100), default block count
+    common[1] = "100"
+    one100 = last_json([sys.executable, bench] + common)
+    three = last_json([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                       "--master-port", "29534", bench, "--gpus", "3", "--backend", "gloo", "--share-device"] + common)
+    assert three["n_gpus"] == 3 and three["frame_checksum"] == one100["frame_checksum"]
 
 
 def test_drt_render_program_checkpoint_and_resume(tmp_path):
