@@ -60,19 +60,19 @@ enum
  * COMPUTED distance is finite always lies inside its boxes. */
 struct BvhNode
 {
-    double  lo[2][3], hi[2][3]; /* the two children's boxes */
+    float   lo[2][3], hi[2][3]; /* the two children's boxes, rounded OUTWARD to f32 (they only prune; tests run in f64) */
     int32_t child[2];           /* inner child: node index; leaf child: first slot in bvh_leaf */
     int32_t count[2];           /* 0: inner child, > 0: leaf with that many surfaces, < 0: no child */
-    int32_t pad[4];             /* 128 bytes: a node is one cache line */
-};
+};                              /* 64 bytes: half a cache line per visit */
 
-/* A surface as the leaves see it: its SoA fields gathered into one 128-byte record, records of a leaf adjacent -- a
- * lane walking the tree on its own touches one cache line per sphere instead of one per field. */
+/* A surface as the leaves see it: a sphere's four numbers gathered into one 64-byte record, records of a leaf adjacent --
+ * a lane walking the tree on its own touches half a cache line per sphere instead of one line per SoA field. */
 struct BvhLeafPrim
 {
     uint32_t index, type;
-    double   f[SF_COUNT];
-};
+    double   f[4]; /* a sphere's centre and radius; a plane's many fields are read from the SoA tables (planes are few) */
+    double   pad[3];
+};             /* 64 bytes */
 
 struct DevMaterial
 {
@@ -189,19 +189,18 @@ __device__ __forceinline__ double surface_distance(const SceneView &sv, uint32_t
 
 #define BVH_STACK 48
 
-__device__ __forceinline__ double leaf_distance(const BvhLeafPrim &lp, V3 o, V3 d)
+__device__ __forceinline__ double leaf_distance(const SceneView &sv, const BvhLeafPrim &lp, V3 o, V3 d)
 {
     if (lp.type == DRT_GEO_SPHERE) return line_sphere(o, d, v3(lp.f[SF_PX], lp.f[SF_PY], lp.f[SF_PZ]), lp.f[SF_RADIUS]);
-    return line_plane(o, d, v3(lp.f[SF_PX], lp.f[SF_PY], lp.f[SF_PZ]), v3(lp.f[SF_NX], lp.f[SF_NY], lp.f[SF_NZ]),
-                      v3(lp.f[SF_UNX], lp.f[SF_UNY], lp.f[SF_UNZ]), v3(lp.f[SF_VNX], lp.f[SF_VNY], lp.f[SF_VNZ]), lp.f[SF_ULEN], lp.f[SF_VLEN]);
+    return surface_distance(sv, lp.index, lp.type, o, d);
 }
 
 /* ray vs padded box: entry distance, or a negative number when the box is missed / behind the ray */
 __device__ __forceinline__ double bvh_box_entry(const BvhNode &n, int c, V3 o, V3 inv_d)
 {
-    double t0x = (n.lo[c][0] - o.x) * inv_d.x, t1x = (n.hi[c][0] - o.x) * inv_d.x;
-    double t0y = (n.lo[c][1] - o.y) * inv_d.y, t1y = (n.hi[c][1] - o.y) * inv_d.y;
-    double t0z = (n.lo[c][2] - o.z) * inv_d.z, t1z = (n.hi[c][2] - o.z) * inv_d.z;
+    double t0x = ((double)n.lo[c][0] - o.x) * inv_d.x, t1x = ((double)n.hi[c][0] - o.x) * inv_d.x;
+    double t0y = ((double)n.lo[c][1] - o.y) * inv_d.y, t1y = ((double)n.hi[c][1] - o.y) * inv_d.y;
+    double t0z = ((double)n.lo[c][2] - o.z) * inv_d.z, t1z = ((double)n.hi[c][2] - o.z) * inv_d.z;
     double tmin = __builtin_fmax(__builtin_fmax(__builtin_fmin(t0x, t1x), __builtin_fmin(t0y, t1y)), __builtin_fmin(t0z, t1z));
     double tmax = __builtin_fmin(__builtin_fmin(__builtin_fmax(t0x, t1x), __builtin_fmax(t0y, t1y)), __builtin_fmax(t0z, t1z));
     if (!(tmax >= 0.0) || !(tmin <= tmax)) return -1.0;
@@ -281,7 +280,7 @@ __device__ __forceinline__ void bvh_closest(const SceneView &sv, V3 o, V3 d, dou
             for (int k = 0; k < count; k += 1)
             {
                 const BvhLeafPrim &lp = sv.bvh_leaf[first + k];
-                double dist = leaf_distance(lp, o, d);
+                double dist = leaf_distance(sv, lp, o, d);
                 if (dist < min_dist || (dist == min_dist && (int)lp.index < index))
                 {
                     min_dist = dist;
@@ -334,7 +333,7 @@ __device__ __forceinline__ bool bvh_occluded(const SceneView &sv, V3 o, V3 d, do
             const int packed = -2 - cur;
             const int first = packed >> 3, count = (packed & 7) + 1;
             for (int k = 0; k < count; k += 1)
-                if (leaf_distance(sv.bvh_leaf[first + k], o, d) < vis_dist) return true;
+                if (leaf_distance(sv, sv.bvh_leaf[first + k], o, d) < vis_dist) return true;
             cur = sp > 0 ? stack[--sp] : BVH_DONE;
         }
         if (cur == BVH_DONE) return false;

@@ -167,7 +167,7 @@ struct BvhBuilder
     std::vector<BuildPrim> prims;
     std::vector<BvhNode>   nodes;
     std::vector<uint32_t>  order;
-    int LEAF = 4; /* surfaces per leaf (<= 8: the traversal packs the count in 3 bits) */
+    int LEAF = 2; /* surfaces per leaf (<= 8: the traversal packs the count in 3 bits) */
 
     void bounds(size_t b, size_t e, double lo[3], double hi[3]) const
     {
@@ -184,7 +184,15 @@ struct BvhBuilder
     {
         double lo[3], hi[3];
         bounds(b, e, lo, hi);
-        for (int k = 0; k < 3; k += 1) { nodes[parent].lo[c][k] = lo[k]; nodes[parent].hi[c][k] = hi[k]; }
+        for (int k = 0; k < 3; k += 1)
+        {
+            /* outward to f32: the stored box must contain the (already padded) f64 box */
+            float fl = (float)lo[k], fh = (float)hi[k];
+            if ((double)fl > lo[k]) fl = std::nextafterf(fl, -INFINITY);
+            if ((double)fh < hi[k]) fh = std::nextafterf(fh, INFINITY);
+            nodes[parent].lo[c][k] = fl;
+            nodes[parent].hi[c][k] = fh;
+        }
         if (e - b <= (size_t)LEAF)
         {
             nodes[parent].child[c] = (int32_t)order.size();
@@ -488,7 +496,7 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene)
             const uint32_t i = bb.order[k];
             leaf[k].index = i;
             leaf[k].type = stype[i];
-            for (int f = 0; f < SF_COUNT; f += 1) leaf[k].f[f] = surf[(size_t)f * n_surf + i];
+            for (int f = 0; f < 4; f += 1) leaf[k].f[f] = surf[(size_t)f * n_surf + i]; /* SF_PX, SF_PY, SF_PZ, SF_RADIUS */
         }
         if ((rc = upload(ctx, bb.nodes, &d.bvh_nodes))) return rc;
         if ((rc = upload(ctx, leaf, &d.bvh_leaf))) return rc;
