@@ -21,6 +21,9 @@ def _rgb(r):
 
 def random_scene_text(seed):
     r = np.random.default_rng(seed)
+    r2 = np.random.default_rng(10 ** 6 + seed)  # later additions draw from their own stream, so older seeds keep their geometry
+    sky = r2.random() < 0.35                    # an emitting escape material: paths that leave the scene pick up light
+    glow = r2.random() < 0.4                    # a surface that emits AND scatters (emissive, not a black body)
     out = []
     # the box first (half size h), then a camera inside it near the open/front side, looking at the middle
     h = r.uniform(3.5, 5.0)
@@ -29,7 +32,7 @@ def random_scene_text(seed):
     lens = r.random() < 0.3
     out.append("Camera\nposition %.4f, %.4f, %.4f\ntarget %.4f, %.4f, %.4f\nroll %.2f\nfov %.1f\nfdepth %.3f\nflength 0.3\naperture %.3f\n" % (
         *pos, *tgt, r.uniform(-30, 30), r.uniform(45, 95), np.linalg.norm(pos - tgt), 0.06 if lens else 0.0))
-    out.append(HEADER)
+    out.append(HEADER.replace("escape_material", "emission constant %.3f\nescape_material" % r2.uniform(0.05, 0.6)) if sky else HEADER)
     mats = []
 
     def mat(name, body):
@@ -52,6 +55,9 @@ def random_scene_text(seed):
                               "emission constant %.3f" % r.uniform(0.05, 2.0)]):
         out.append("Material\nname light%d\n%s\nis_black_body true\n" % (k, body))
         lights.append("light%d" % k)
+    if glow:
+        out.append("Material\nname glow\nemission %s scale %.2f\ndiffuse %s\nglossy %s\nshininess 12.0\nbdsfs bp_diffuse_bdsf, bp_glossy_bdsf\n"
+                   "dir_func cos_weighted_sample_hemisphere\n" % (_rgb(r2), r2.uniform(0.5, 3.0), _rgb(r2), _rgb(r2)))
     surf = []
 
     def plane(name, p, u, v, m):
@@ -80,6 +86,9 @@ def random_scene_text(seed):
             surf.append("Surface\nname lamp%d\ntype sphere\nposition %.4f, %.4f, %.4f\nradius %.3f\nmaterial %s\n" % (k, *c, r.uniform(0.1, 0.5), m))
         else:
             surf.append("Surface\nname lamp%d\ntype point\nposition %.4f, %.4f, %.4f\nmaterial %s\n" % (k, *c, m))
+    if glow:
+        c = r2.uniform(-2.0, 2.0, 3)
+        surf.append("Surface\nname glowball\ntype sphere\nposition %.4f, %.4f, %.4f\nradius %.3f\nmaterial glow\n" % (*c, r2.uniform(0.3, 0.9)))
     order = r.permutation(len(surf))  # lights and geometry interleaved: light order follows surface order in the reference
     return "\n".join(out) + "\n" + "\n".join(surf[i] for i in order)
 
