@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: all ranks use GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes needs dmabuf IPC on this driver
     import torch
     import pydrt
     import drt_dist
