@@ -680,6 +680,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
     bool exhausted = false; /* wave-uniform: no more work to draw */
     uint64_t pid = 0, rs = 1;
     uint32_t depth = 0, shaded = 0;
+    uint32_t plastic_mask = 0; /* bit v: shaded vertex v (< 16) has the two-lobe plastic list; header bits 48-63, read by the shade kernel's tail pass */
     V3 ro = v3(0, 0, 0), rd = v3(0, 0, 0);
     uint64_t *rec = nullptr, *hdr = nullptr;
 
@@ -752,6 +753,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
                 camera_ray(cam, tp.pixel_scheme, x, y, rs, n_draws, ro, rd);
                 depth = 0;
                 shaded = 0;
+                plastic_mask = 0;
                 uint64_t slot = q * (uint64_t)tp.batch + s_local;
                 rec = records + slot * (uint64_t)tp.path_words;
                 hdr = headers + slot * REC_HEADER_WORDS;
@@ -850,6 +852,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
                 vrec[3] = (uint64_t)__double_as_longlong(ip.on_dot);
                 vrec[4] = (uint64_t)__double_as_longlong(dir_pdf);
                 store_coef(vrec + 5, e);
+                if ((mat.vertex_flags & FLAG_PLASTIC) && shaded < 16u) plastic_mask |= 1u << shaded;
                 shaded += 1;
                 rd = in;
                 ro = ip.position;
@@ -857,7 +860,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
             depth += 1;
             if (terminal || depth >= tp.max_depth)
             {
-                hdr[0] = (uint64_t)shaded | ((uint64_t)term << 16) | ((uint64_t)(term_spd & 0xFFFFu) << 32);
+                hdr[0] = (uint64_t)shaded | ((uint64_t)term << 16) | ((uint64_t)(term_spd & 0xFFFFu) << 32) | ((uint64_t)plastic_mask << 48);
                 alive = false;
             }
         }
@@ -890,6 +893,7 @@ struct ShadeParams
     uint32_t n_lights, batch;
     uint32_t tail_first, tail_count; /* wavelengths [tail_first, tail_first + tail_count) go through the packed tail pass (0: none) */
     uint32_t chunk, sub_pixels;      /* pixels per group (= tail packing size when there is a tail); pixels per main-pass work item */
+    double  *tail_stage;                  /* [n_pix * batch][tail_count]: per-sample results of the tail pass (see the kernel) */
     uint32_t cmf_rw, cmf_x, cmf_y, cmf_z; /* XYZ film mode: SPD rows of the white table and the colour-matching functions */
     uint32_t tail_period_mains, pad1;  /* split queue with a tail: main-pass items between two tail items (<= main items per group) */
     uint32_t items_per_group, n_items; /* work items: per group of `chunk` pixels, ceil(chunk/sub_pixels) main-pass items and, with a tail,
@@ -997,6 +1001,194 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
 
 #define XYZ_FILM_WORDS 8 /* XYZ film mode, per pixel: X, Y, Z numerators of the main pass, filter sum, X, Y, Z of the tail pass, unused */
 
+/*
+ * Tail pass. S = 69 leaves 5 wavelengths beyond the 64 lanes; giving them a second register set would cost every vector
+ * instruction again for 5 useful lanes. Instead the tails of a group's pixels are packed into one wave: lane = (pixel g of
+ * the group, tail wavelength j). Each lane replays ITS pixel's records, read per lane, with the same per-wavelength
+ * arithmetic in the same order. It is a work item of the shade kernel's queue, sharing the SIMDs with main-pass waves
+ * (as a kernel of its own, at 4 to 8 waves per SIMD, it was 12-27 ms slower: measured).
+ */
+template <bool SPDS_IN_LDS, bool XYZ>
+__device__ __forceinline__ void shade_tail_group(const DevScene &sc, const ShadeParams &sp, const double *lds, const uint64_t *__restrict__ records,
+                                                 const uint64_t *__restrict__ headers, double *__restrict__ film_pixels,
+                                                 double *__restrict__ film_avgs, double *__restrict__ film_vars, uint64_t chunk_base,
+                                                 uint64_t chunk_end, uint32_t lane)
+{
+    const uint32_t S = sc.S;
+    const uint32_t vw = sp.vertex_words;
+    const uint32_t R = sp.tail_count;
+    const uint32_t g = lane / R, j = lane - g * R;
+    const uint64_t pix_l = chunk_base + g;
+    const bool act = g < (uint32_t)(chunk_end - chunk_base) && g < 64u / R;
+    const uint32_t lam = sp.tail_first + j; /* < S by construction */
+    const double *table = SPDS_IN_LDS ? (const double *)lds : sc.spds;
+    double *px = film_pixels + pix_l * (uint64_t)(XYZ ? XYZ_FILM_WORDS : S + 1);
+    double *pa = XYZ ? nullptr : film_avgs + pix_l * (uint64_t)S;
+    double *pv = XYZ ? nullptr : film_vars + pix_l * (uint64_t)S;
+    /*
+     * Phase A -- radiance, paced per pixel. If the 12 pixels stepped through their samples together, every sample
+     * would cost the longest of 12 paths (about 4.5 vertices where the average is 1.65), and every vertex step both
+     * the two-lobe plastic's code and the general BDSF code, because some pixel or other is always on glass or gold.
+     * Instead each pixel's lanes keep their own (sample, vertex) cursor; the header says which of the path's first 16
+     * vertices are plastic (bits 48-63), so an iteration is EITHER a plastic step or a general step -- whichever more
+     * lanes are waiting for -- and then closes the samples that are complete (emission, vignette; result parked in
+     * tail_stage). The wave runs for the pixel with the most vertices in the batch, and the general code only runs
+     * when it is what most lanes need.
+     */
+    double *stage = sp.tail_stage + (pix_l * (uint64_t)sp.batch) * R + j;
+    uint32_t s = act ? 0u : sp.n_samples; /* lanes without a pixel are done from the start */
+    uint32_t v = 0, n_shaded = 0, term = 0, term_spd = 0, plastic_mask = 0;
+    double vignette = 0.0, throughput = 1.0, dst = 0.0;
+    const uint64_t *rp = records;
+    auto open_sample = [&]() {
+        const uint64_t slot = pix_l * sp.batch + s;
+        const uint64_t h0 = headers[slot * REC_HEADER_WORDS], h1 = headers[slot * REC_HEADER_WORDS + 1];
+        n_shaded = (uint32_t)(h0 & 0xFFFFu);
+        term = (uint32_t)(h0 >> 16) & 0xFFu;
+        term_spd = (uint32_t)(h0 >> 32) & 0xFFFFu;
+        plastic_mask = (uint32_t)(h0 >> 48);
+        vignette = word_as_double(h1);
+        rp = records + slot * (uint64_t)sp.path_words;
+        v = 0;
+        throughput = 1.0;
+        dst = 0.0;
+    };
+    if (s < sp.n_samples) open_sample();
+    while (__any(s < sp.n_samples))
+    {
+        const bool has_vertex = s < sp.n_samples && v < n_shaded;
+        const bool is_plastic = has_vertex && v < 16u && ((plastic_mask >> v) & 1u);
+        const bool is_general = has_vertex && !is_plastic;
+        const uint32_t n_plastic = (uint32_t)__popcll(__ballot(is_plastic)), n_general = (uint32_t)__popcll(__ballot(is_general));
+        if (n_plastic > 0 && n_plastic >= n_general)
+        {
+            if (is_plastic)
+            {
+                /* bdsf() over {bp_diffuse_bdsf, bp_glossy_bdsf}, straight-line (as in the main pass) */
+                const uint64_t *vrec = rp + (uint64_t)v * vw;
+                const uint64_t w1 = vrec[1];
+                const double dir_pdf = word_as_double(vrec[4]);
+                const double s_a_in = word_as_double(vrec[5]), s_spec = word_as_double(vrec[6]);
+                const uint32_t i_diffuse = (uint32_t)(w1 >> 16) & 0xFFFFu, i_glossy = (uint32_t)(w1 >> 32) & 0xFFFFu;
+                const double diffuse_pi = spd_at(table, S, i_diffuse, lam), glossy = spd_at(table, S, i_glossy, lam);
+                double contribution = 0.0;
+                for (uint32_t l = 0; l < sp.n_lights; l += 1)
+                {
+                    const uint64_t *lrec = vrec + REC_VERTEX_WORDS + l * REC_LIGHT_WORDS;
+                    const uint64_t lw0 = lrec[0];
+                    if (!((uint32_t)(lw0 >> 16) & FLAG_VISIBLE)) continue;
+                    const double c = word_as_double(lrec[1]), a_in = word_as_double(lrec[2]), spec = word_as_double(lrec[3]);
+                    double reflectance = diffuse_pi * a_in + 0.0;
+                    reflectance = (glossy * spec) * a_in + reflectance;
+                    contribution = contribution + reflectance;
+                    contribution = contribution * spd_at(table, S, (uint32_t)(lw0 & 0xFFFFu), lam);
+                    contribution = contribution * c;
+                }
+                dst = dst + throughput * contribution;
+                double reflectance = diffuse_pi * s_a_in + 0.0;
+                reflectance = (glossy * s_spec) * s_a_in + reflectance;
+                reflectance = reflectance * dir_pdf;
+                throughput = throughput * reflectance;
+                v += 1;
+            }
+        }
+        else if (n_general > 0)
+        {
+            if (is_general)
+            {
+                /* any BDSF list (also plastic vertices beyond the header's 16 flags) */
+                const uint64_t *vrec = rp + (uint64_t)v * vw;
+                const uint64_t list = vrec[0], w1 = vrec[1], w2 = vrec[2];
+                const double on_dot = word_as_double(vrec[3]), dir_pdf = word_as_double(vrec[4]);
+                const double s_a_in = word_as_double(vrec[5]), s_spec = word_as_double(vrec[6]);
+                const uint32_t num_bdsfs = (uint32_t)(w1 & 0xFFu);
+                const uint32_t sflags = (uint32_t)(w1 >> 8) & 0xFFu;
+                const uint32_t i_diffuse = (uint32_t)(w1 >> 16) & 0xFFFFu, i_glossy = (uint32_t)(w1 >> 32) & 0xFFFFu;
+                const double diffuse_pi = spd_at(table, S, i_diffuse, lam), glossy = spd_at(table, S, i_glossy, lam);
+                const double mirror = spd_at(table, S, (uint32_t)(w1 >> 48) & 0xFFFFu, lam);
+                const double ir = spd_at(table, S, (uint32_t)(w2)&0xFFFFu, lam), tr = spd_at(table, S, (uint32_t)(w2 >> 16) & 0xFFFFu, lam);
+                const double te = spd_at(table, S, (uint32_t)(w2 >> 32) & 0xFFFFu, lam);
+                double contribution = 0.0;
+                for (uint32_t l = 0; l < sp.n_lights; l += 1)
+                {
+                    const uint64_t *lrec = vrec + REC_VERTEX_WORDS + l * REC_LIGHT_WORDS;
+                    const uint64_t lw0 = lrec[0];
+                    const uint32_t lflags = (uint32_t)(lw0 >> 16) & 0xFFu;
+                    if (!(lflags & FLAG_VISIBLE)) continue;
+                    double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse_pi, glossy, mirror, ir, tr, te, on_dot,
+                                                            word_as_double(lrec[2]), word_as_double(lrec[3]), word_as_double(lrec[4]),
+                                                            word_as_double(lrec[5]), lflags);
+                    contribution = contribution + reflectance;
+                    contribution = contribution * spd_at(table, S, (uint32_t)(lw0 & 0xFFFFu), lam);
+                    contribution = contribution * word_as_double(lrec[1]);
+                }
+                dst = dst + throughput * contribution;
+                double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse_pi, glossy, mirror, ir, tr, te, on_dot, s_a_in, s_spec,
+                                                        word_as_double(vrec[7]), word_as_double(vrec[8]), sflags);
+                reflectance = reflectance * dir_pdf;
+                throughput = throughput * reflectance;
+                v += 1;
+            }
+        }
+        if (s < sp.n_samples && v >= n_shaded)
+        {
+            /* the path's last vertex is done (or it had none): close the sample, :452-457 and :615 */
+            if (term == 1) dst = dst + throughput * spd_at(table, S, term_spd, lam);
+            stage[(uint64_t)s * R] = dst * vignette;
+            s += 1;
+            if (s < sp.n_samples) open_sample();
+        }
+    }
+    /* Phase B -- the film update (src/daily_ray_trace.c:732-743), the pixels' samples in order, all pixels in step */
+    double f_sum = (act && !XYZ) ? px[lam] : 0.0, f_avg = (act && !XYZ) ? pa[lam] : 0.0, f_var = (act && !XYZ) ? pv[lam] : 0.0;
+#pragma unroll 4
+    for (uint32_t k = 0; k < sp.n_samples; k += 1)
+    {
+        const double contribution = act ? stage[(uint64_t)k * R] : 0.0;
+        const double denom = (double)(sp.first_sample + k + 1);
+        f_sum = f_sum + contribution;
+        if (!XYZ)
+        {
+            double t0 = contribution - f_avg;
+            double t1 = t0;
+            t0 = t0 / denom;
+            f_avg = f_avg + t0;
+            t0 = contribution - f_avg;
+            t0 = t1 * t0;
+            f_var = f_var + t0;
+        }
+    }
+    if (XYZ)
+    {
+        /* the pixel's tail wavelengths, summed over its R lanes by the group's first lane */
+        const double rw = spd_at(table, S, sp.cmf_rw, lam);
+        const double x = act ? (spd_at(table, S, sp.cmf_x, lam) * f_sum * rw) : 0.0;
+        const double y = act ? (spd_at(table, S, sp.cmf_y, lam) * f_sum * rw) : 0.0;
+        const double z = act ? (spd_at(table, S, sp.cmf_z, lam) * f_sum * rw) : 0.0;
+        double X = 0.0, Y = 0.0, Z = 0.0;
+        for (uint32_t t = 0; t < R; t += 1)
+        {
+            const int src = (int)((lane - j + t) & 63u);
+            X += __shfl(x, src);
+            Y += __shfl(y, src);
+            Z += __shfl(z, src);
+        }
+        if (act && j == 0)
+        {
+            px[4] += X;
+            px[5] += Y;
+            px[6] += Z;
+        }
+    }
+    else if (act)
+    {
+        px[lam] = f_sum;
+        pa[lam] = f_avg;
+        pv[lam] = f_var;
+    }
+}
+
+
 template <int NSETS, bool SPDS_IN_LDS, bool XYZ>
 __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_shade_kernel(DevScene sc, ShadeParams sp, const uint64_t *__restrict__ records,
                                                                  const uint64_t *__restrict__ headers, double *__restrict__ film_pixels,
@@ -1037,13 +1229,14 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
          * every period of 1 + tail_period_mains items, between main-pass pieces so that latency-bound tail waves and
          * arithmetic-bound main waves share the SIMDs -- and the launch ends on main-pass pieces only */
         const bool split = sp.items_per_group > 1;
-        const uint32_t mains_per_group = sp.items_per_group - (sp.tail_count ? 1u : 0u);
-        bool tail_item = sp.tail_count != 0;
+        const bool inline_tail = sp.tail_count != 0;
+        const uint32_t mains_per_group = sp.items_per_group - (inline_tail ? 1u : 0u);
+        bool tail_item = inline_tail;
         uint32_t group = item, sub = 0;
         if (split)
         {
             uint32_t m = item; /* index among the main-pass pieces */
-            if (sp.tail_count)
+            if (inline_tail)
             {
                 const uint32_t n_groups = sp.n_items / sp.items_per_group;
                 const uint32_t q = sp.tail_period_mains, mixed = n_groups * (q + 1u);
@@ -1356,143 +1549,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
         }
       }
 
-        /*
-         * Tail pass. S = 69 leaves 5 wavelengths beyond the 64 lanes; giving them a second register set would
-         * cost every vector instruction again for 5 useful lanes. Instead the tails of the chunk's pixels are
-         * packed into one wave: lane = (pixel g of the chunk, tail wavelength j). Each lane replays ITS pixel's
-         * records, read per lane from HBM/L2 (the main pass just touched them), with the same per-wavelength
-         * arithmetic in the same order; lanes of different pixels may diverge on material and path length.
-         */
-        if (tail_item)
-        {
-            const uint32_t R = sp.tail_count;
-            const uint32_t g = lane / R, j = lane - g * R;
-            const uint64_t pix_l = chunk_base + g;
-            const bool act = g < (uint32_t)(chunk_end - chunk_base) && g < 64u / R;
-            const uint32_t lam = sp.tail_first + j; /* < S by construction */
-            const double *table = SPDS_IN_LDS ? (const double *)lds : sc.spds;
-            double *px = film_pixels + pix_l * (uint64_t)(XYZ ? XYZ_FILM_WORDS : S + 1);
-            double *pa = XYZ ? nullptr : film_avgs + pix_l * (uint64_t)S;
-            double *pv = XYZ ? nullptr : film_vars + pix_l * (uint64_t)S;
-            double f_sum = (act && !XYZ) ? px[lam] : 0.0, f_avg = (act && !XYZ) ? pa[lam] : 0.0, f_var = (act && !XYZ) ? pv[lam] : 0.0;
-            for (uint32_t s = 0; s < sp.n_samples; s += 1)
-            {
-                const uint64_t slot = pix_l * sp.batch + s;
-                uint64_t h0 = 0, h1 = 0;
-                if (act)
-                {
-                    h0 = headers[slot * REC_HEADER_WORDS];
-                    h1 = headers[slot * REC_HEADER_WORDS + 1];
-                }
-                const uint32_t n_shaded = (uint32_t)(h0 & 0xFFFFu);
-                const uint32_t term = (uint32_t)(h0 >> 16) & 0xFFu;
-                const uint32_t term_spd = (uint32_t)(h0 >> 32) & 0xFFFFu;
-                const uint64_t *rp = records + slot * (uint64_t)sp.path_words;
-                double throughput = 1.0, dst = 0.0;
-                for (uint32_t v = 0; __any(v < n_shaded); v += 1)
-                {
-                    if (v >= n_shaded) continue;
-                    const uint64_t *vrec = rp + (uint64_t)v * vw;
-                    const uint64_t list = vrec[0], w1 = vrec[1];
-                    const double dir_pdf = word_as_double(vrec[4]);
-                    const double s_a_in = word_as_double(vrec[5]), s_spec = word_as_double(vrec[6]);
-                    const uint32_t num_bdsfs = (uint32_t)(w1 & 0xFFu);
-                    const uint32_t sflags = (uint32_t)(w1 >> 8) & 0xFFu;
-                    const uint32_t i_diffuse = (uint32_t)(w1 >> 16) & 0xFFFFu, i_glossy = (uint32_t)(w1 >> 32) & 0xFFFFu;
-                    double contribution = 0.0;
-                    if (sflags & FLAG_PLASTIC)
-                    {
-                        const double diffuse_pi = spd_at(table, S, i_diffuse, lam), glossy = spd_at(table, S, i_glossy, lam);
-                        for (uint32_t l = 0; l < sp.n_lights; l += 1)
-                        {
-                            const uint64_t *lrec = vrec + REC_VERTEX_WORDS + l * REC_LIGHT_WORDS;
-                            const uint64_t lw0 = lrec[0];
-                            if (!((uint32_t)(lw0 >> 16) & FLAG_VISIBLE)) continue;
-                            const double c = word_as_double(lrec[1]), a_in = word_as_double(lrec[2]), spec = word_as_double(lrec[3]);
-                            double reflectance = diffuse_pi * a_in + 0.0;
-                            reflectance = (glossy * spec) * a_in + reflectance;
-                            contribution = contribution + reflectance;
-                            contribution = contribution * spd_at(table, S, (uint32_t)(lw0 & 0xFFFFu), lam);
-                            contribution = contribution * c;
-                        }
-                        dst = dst + throughput * contribution;
-                        double reflectance = diffuse_pi * s_a_in + 0.0;
-                        reflectance = (glossy * s_spec) * s_a_in + reflectance;
-                        reflectance = reflectance * dir_pdf;
-                        throughput = throughput * reflectance;
-                    }
-                    else
-                    {
-                        const uint64_t w2 = vrec[2];
-                        const double on_dot = word_as_double(vrec[3]);
-                        const double diffuse_pi = spd_at(table, S, i_diffuse, lam), glossy = spd_at(table, S, i_glossy, lam);
-                        const double mirror = spd_at(table, S, (uint32_t)(w1 >> 48) & 0xFFFFu, lam);
-                        const double ir = spd_at(table, S, (uint32_t)(w2)&0xFFFFu, lam), tr = spd_at(table, S, (uint32_t)(w2 >> 16) & 0xFFFFu, lam);
-                        const double te = spd_at(table, S, (uint32_t)(w2 >> 32) & 0xFFFFu, lam);
-                        for (uint32_t l = 0; l < sp.n_lights; l += 1)
-                        {
-                            const uint64_t *lrec = vrec + REC_VERTEX_WORDS + l * REC_LIGHT_WORDS;
-                            const uint64_t lw0 = lrec[0];
-                            const uint32_t lflags = (uint32_t)(lw0 >> 16) & 0xFFu;
-                            if (!(lflags & FLAG_VISIBLE)) continue;
-                            double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse_pi, glossy, mirror, ir, tr, te, on_dot,
-                                                                    word_as_double(lrec[2]), word_as_double(lrec[3]), word_as_double(lrec[4]),
-                                                                    word_as_double(lrec[5]), lflags);
-                            contribution = contribution + reflectance;
-                            contribution = contribution * spd_at(table, S, (uint32_t)(lw0 & 0xFFFFu), lam);
-                            contribution = contribution * word_as_double(lrec[1]);
-                        }
-                        dst = dst + throughput * contribution;
-                        double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse_pi, glossy, mirror, ir, tr, te, on_dot, s_a_in, s_spec,
-                                                                word_as_double(vrec[7]), word_as_double(vrec[8]), sflags);
-                        reflectance = reflectance * dir_pdf;
-                        throughput = throughput * reflectance;
-                    }
-                }
-                if (term == 1) dst = dst + throughput * spd_at(table, S, term_spd, lam);
-                const double contribution = dst * word_as_double(h1);
-                const double denom = (double)(sp.first_sample + s + 1);
-                f_sum = f_sum + contribution;
-                if (!XYZ)
-                {
-                    double t0 = contribution - f_avg;
-                    double t1 = t0;
-                    t0 = t0 / denom;
-                    f_avg = f_avg + t0;
-                    t0 = contribution - f_avg;
-                    t0 = t1 * t0;
-                    f_var = f_var + t0;
-                }
-            }
-            if (XYZ)
-            {
-                /* the pixel's tail wavelengths, summed over its R lanes by the group's first lane */
-                const double rw = spd_at(table, S, sp.cmf_rw, lam);
-                const double x = act ? (spd_at(table, S, sp.cmf_x, lam) * f_sum * rw) : 0.0;
-                const double y = act ? (spd_at(table, S, sp.cmf_y, lam) * f_sum * rw) : 0.0;
-                const double z = act ? (spd_at(table, S, sp.cmf_z, lam) * f_sum * rw) : 0.0;
-                double X = 0.0, Y = 0.0, Z = 0.0;
-                for (uint32_t t = 0; t < R; t += 1)
-                {
-                    const int src = (int)((lane - j + t) & 63u);
-                    X += __shfl(x, src);
-                    Y += __shfl(y, src);
-                    Z += __shfl(z, src);
-                }
-                if (act && j == 0)
-                {
-                    px[4] += X;
-                    px[5] += Y;
-                    px[6] += Z;
-                }
-            }
-            else if (act)
-            {
-                px[lam] = f_sum;
-                pa[lam] = f_avg;
-                pv[lam] = f_var;
-            }
-        }
+        if (tail_item) shade_tail_group<SPDS_IN_LDS, XYZ>(sc, sp, (const double *)lds, records, headers, film_pixels, film_avgs, film_vars, chunk_base, chunk_end, lane);
     }
 }
 

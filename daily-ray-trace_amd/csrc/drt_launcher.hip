@@ -54,6 +54,7 @@ struct drt_context
     bool    xyz_mode = false;
     bool    own_film = false;
     uint64_t *d_records = nullptr, *d_headers = nullptr;
+    double   *d_tail_stage = nullptr; /* [n_pix * batch][tail_count]: per-sample results of the shade kernel's tail pass */
     uint32_t  batch_spp = 1;
     uint32_t  vertex_words = 0, path_words = 0;
     int32_t  *d_hits = nullptr;
@@ -671,6 +672,7 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     ctx->shade_lds = ctx->spds_in_lds ? (size_t)ctx->dsc.n_spd * S * 8 : 0;
     int s_per_cu = 0;
     shade_sets(S, &ctx->shade_sets, &ctx->tail_first, &ctx->tail_count);
+    if (ctx->tail_count) HIP_TRY(hipMalloc((void **)&ctx->d_tail_stage, (size_t)ctx->n_pix * ctx->batch_spp * ctx->tail_count * 8));
     switch (ctx->shade_sets)
     {
         case 1: rc = shade_occupancy<1>(ctx, &s_per_cu); break;
@@ -731,6 +733,7 @@ extern "C" void drt_destroy(drt_context *ctx)
     }
     (void)hipFree(ctx->d_records);
     (void)hipFree(ctx->d_headers);
+    (void)hipFree(ctx->d_tail_stage);
     (void)hipFree(ctx->d_hits);
     (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_xyz);
@@ -873,9 +876,11 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
         sp.batch = ctx->batch_spp;
         sp.tail_first = ctx->tail_first;
         sp.tail_count = ctx->tail_count;
+        sp.tail_stage = ctx->d_tail_stage;
         sp.cmf_rw = ctx->cmf_rw; sp.cmf_x = ctx->cmf_x; sp.cmf_y = ctx->cmf_y; sp.cmf_z = ctx->cmf_z;
         sp.chunk = ctx->tail_count ? 64u / ctx->tail_count : SHADE_PIXEL_CHUNK;
         uint64_t groups = (ctx->n_pix + sp.chunk - 1) / sp.chunk;
+        const bool inline_tail = ctx->tail_count != 0;
         /* work items: a group's main pass in pieces of sub_pixels pixels (+ its tail pass as an item of its own) when the
          * groups alone are too few to keep the last round of the persistent waves short */
         {
@@ -889,10 +894,10 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
                 uint64_t p_atomic = (256 + n - 1) / n;
                 uint32_t P = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(std::max(p_balance, p_atomic), 1), sp.chunk);
                 subs = (sp.chunk + P - 1) / P;
-                if (subs == 1 && !ctx->tail_count) subs = 0;
+                if (subs == 1 && !inline_tail) subs = 0;
             }
             subs = std::min(subs, sp.chunk);
-            if (subs == 0 || (subs == 1 && !ctx->tail_count) || groups * (uint64_t)(sp.chunk + 1) >= 0xFFFFFFFFull)
+            if (subs == 0 || (subs == 1 && !inline_tail) || groups * (uint64_t)(sp.chunk + 1) >= 0xFFFFFFFFull)
             {
                 sp.sub_pixels = sp.chunk;
                 sp.items_per_group = 1;
@@ -900,11 +905,11 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
             else
             {
                 sp.sub_pixels = (sp.chunk + subs - 1) / subs;
-                sp.items_per_group = (sp.chunk + sp.sub_pixels - 1) / sp.sub_pixels + (ctx->tail_count ? 1 : 0);
+                sp.items_per_group = (sp.chunk + sp.sub_pixels - 1) / sp.sub_pixels + (inline_tail ? 1 : 0);
             }
             if (groups * sp.items_per_group >= 0xFFFFFFFFull) return fail(-1, "tile too large for the shade work queue");
             sp.n_items = (uint32_t)(groups * sp.items_per_group);
-            if (ctx->tail_count && sp.items_per_group > 1)
+            if (inline_tail && sp.items_per_group > 1)
             {
                 uint32_t mains = sp.items_per_group - 1;
                 sp.tail_period_mains = std::max<uint32_t>(1, mains * 4 / 5); /* the last fifth of the queue is main-pass pieces only */
