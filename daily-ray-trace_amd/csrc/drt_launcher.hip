@@ -912,7 +912,9 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
             if (inline_tail && sp.items_per_group > 1)
             {
                 uint32_t mains = sp.items_per_group - 1;
-                sp.tail_period_mains = std::max<uint32_t>(1, mains * 4 / 5); /* the last fifth of the queue is main-pass pieces only */
+                /* tail items (the longest ones) evenly through the queue when every wave gets many of them; when a wave gets
+                 * only a few (small tiles), the last fifth of the queue is main-pass pieces only, so the launch ends on short items */
+                sp.tail_period_mains = (groups >= 8 * waves) ? mains : std::max<uint32_t>(1, mains * 4 / 5);
                 if (ctx->tail_period_override) sp.tail_period_mains = std::min(mains, ctx->tail_period_override);
             }
         }
