@@ -1326,6 +1326,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
             const uint32_t n_shaded = (uint32_t)(hs & 0xFFFFu);
             const uint32_t term = (uint32_t)(hs >> 16) & 0xFFu;
             const uint32_t term_spd = (uint32_t)(hs >> 32) & 0xFFFFu;
+            const uint32_t plastic_mask = (uint32_t)(hs >> 48); /* bit v: vertex v has the two-lobe plastic list */
             const uint64_t *p_s = rbase + (uint64_t)s * sp.path_words;
             /* rotate the ring, then start the load for the sample SHADE_PREFETCH_DEPTH ahead */
 #pragma unroll
@@ -1366,6 +1367,69 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
                     lane0 = 0;
                     src = (lane < vw) ? p_s[(uint64_t)v * vw + lane] : 0;
                 }
+                const double *table = SPDS_IN_LDS ? (const double *)lds : sc.spds;
+                double contribution[NSETS];
+#pragma unroll
+                for (int k = 0; k < NSETS; k += 1) contribution[k] = 0.0;
+                /* the two-lobe plastic, known from the header's flags before a word of the vertex is decoded: only the
+                 * words that list needs travel to the scalar unit */
+                auto plastic_vertex = [&](uint64_t w1, double dir_pdf, double s_a_in, double s_spec) {
+                    const uint32_t i_diffuse = (uint32_t)(w1 >> 16) & 0xFFFFu, i_glossy = (uint32_t)(w1 >> 32) & 0xFFFFu;
+                    /* the common material, straight-line: bdsf() over {bp_diffuse_bdsf, bp_glossy_bdsf}
+                         * = (glossy*spec)*a + ((diffuse/pi)*a + 0), src/bdsf.c:105-119 through src/daily_ray_trace.c:215-229 */
+                        double diffuse_pi[NSETS], glossy[NSETS];
+#pragma unroll
+                        for (int k = 0; k < NSETS; k += 1)
+                        {
+                            diffuse_pi[k] = spd_at(table, S, i_diffuse, lam_c[k]);
+                            glossy[k] = spd_at(table, S, i_glossy, lam_c[k]);
+                        }
+                        for (uint32_t l = 0; l < sp.n_lights; l += 1) /* direct_light_contribution, :272-332 */
+                        {
+                            const uint32_t off = REC_VERTEX_WORDS + l * REC_LIGHT_WORDS;
+                            uint64_t lw[4];
+                            if (off + REC_LIGHT_WORDS <= 64 || v < n_fast)
+                            {
+#pragma unroll
+                                for (int k = 0; k < 4; k += 1) lw[k] = readlane64(src, lane0 + off + k);
+                            }
+                            else
+                            {
+                                const uint64_t *lp = p_s + (uint64_t)v * vw + off;
+#pragma unroll
+                                for (int k = 0; k < 4; k += 1) lw[k] = readlane64(lp[k], 0);
+                            }
+                            if (!((uint32_t)(lw[0] >> 16) & FLAG_VISIBLE)) continue;
+                            const uint32_t i_em = (uint32_t)(lw[0] & 0xFFFFu);
+                            const double c = word_as_double(lw[1]), a_in = word_as_double(lw[2]), spec = word_as_double(lw[3]);
+#pragma unroll
+                            for (int k = 0; k < NSETS; k += 1)
+                            {
+                                double reflectance = diffuse_pi[k] * a_in + 0.0;
+                                reflectance = (glossy[k] * spec) * a_in + reflectance;
+                                contribution[k] = contribution[k] + reflectance;                      /* :323 */
+                                contribution[k] = contribution[k] * spd_at(table, S, i_em, lam_c[k]); /* :324 */
+                                contribution[k] = contribution[k] * c;                                /* :326-327 */
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < NSETS; k += 1)
+                        {
+                            dst[k] = dst[k] + throughput[k] * contribution[k]; /* :461-462 */
+                            double reflectance = diffuse_pi[k] * s_a_in + 0.0;
+                            reflectance = (glossy[k] * s_spec) * s_a_in + reflectance;
+                            reflectance = reflectance * dir_pdf;         /* :468 */
+                            throughput[k] = throughput[k] * reflectance; /* :469 */
+                        }
+                };
+                if (v < 16u && ((plastic_mask >> v) & 1u))
+                {
+                    const uint64_t w1p = readlane64(src, lane0 + 1);
+                    const double dir_pdf_p = word_as_double(readlane64(src, lane0 + 4));
+                    const double s_a_in_p = word_as_double(readlane64(src, lane0 + 5)), s_spec_p = word_as_double(readlane64(src, lane0 + 6));
+                    plastic_vertex(w1p, dir_pdf_p, s_a_in_p, s_spec_p);
+                    continue;
+                }
                 const uint64_t list = readlane64(src, lane0 + 0);
                 const uint64_t w1 = readlane64(src, lane0 + 1);
                 const uint64_t w2 = readlane64(src, lane0 + 2);
@@ -1376,61 +1440,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
                 const uint32_t i_diffuse = (uint32_t)(w1 >> 16) & 0xFFFFu, i_glossy = (uint32_t)(w1 >> 32) & 0xFFFFu;
                 const uint32_t i_mirror = (uint32_t)(w1 >> 48) & 0xFFFFu;
                 const uint32_t i_ir = (uint32_t)(w2)&0xFFFFu, i_tr = (uint32_t)(w2 >> 16) & 0xFFFFu, i_te = (uint32_t)(w2 >> 32) & 0xFFFFu;
-
-                const double *table = SPDS_IN_LDS ? (const double *)lds : sc.spds;
                 const double s_a_in = word_as_double(readlane64(src, lane0 + 5)), s_spec = word_as_double(readlane64(src, lane0 + 6));
-                double contribution[NSETS];
-#pragma unroll
-                for (int k = 0; k < NSETS; k += 1) contribution[k] = 0.0;
 
-                if (sflags & FLAG_PLASTIC)
+                if (sflags & FLAG_PLASTIC) /* a plastic vertex beyond the header's 16 flags */
                 {
-                    /* the common material, straight-line: bdsf() over {bp_diffuse_bdsf, bp_glossy_bdsf}
-                     * = (glossy*spec)*a + ((diffuse/pi)*a + 0), src/bdsf.c:105-119 through src/daily_ray_trace.c:215-229 */
-                    double diffuse_pi[NSETS], glossy[NSETS];
-#pragma unroll
-                    for (int k = 0; k < NSETS; k += 1)
-                    {
-                        diffuse_pi[k] = spd_at(table, S, i_diffuse, lam_c[k]);
-                        glossy[k] = spd_at(table, S, i_glossy, lam_c[k]);
-                    }
-                    for (uint32_t l = 0; l < sp.n_lights; l += 1) /* direct_light_contribution, :272-332 */
-                    {
-                        const uint32_t off = REC_VERTEX_WORDS + l * REC_LIGHT_WORDS;
-                        uint64_t lw[4];
-                        if (off + REC_LIGHT_WORDS <= 64 || v < n_fast)
-                        {
-#pragma unroll
-                            for (int k = 0; k < 4; k += 1) lw[k] = readlane64(src, lane0 + off + k);
-                        }
-                        else
-                        {
-                            const uint64_t *lp = p_s + (uint64_t)v * vw + off;
-#pragma unroll
-                            for (int k = 0; k < 4; k += 1) lw[k] = readlane64(lp[k], 0);
-                        }
-                        if (!((uint32_t)(lw[0] >> 16) & FLAG_VISIBLE)) continue;
-                        const uint32_t i_em = (uint32_t)(lw[0] & 0xFFFFu);
-                        const double c = word_as_double(lw[1]), a_in = word_as_double(lw[2]), spec = word_as_double(lw[3]);
-#pragma unroll
-                        for (int k = 0; k < NSETS; k += 1)
-                        {
-                            double reflectance = diffuse_pi[k] * a_in + 0.0;
-                            reflectance = (glossy[k] * spec) * a_in + reflectance;
-                            contribution[k] = contribution[k] + reflectance;                      /* :323 */
-                            contribution[k] = contribution[k] * spd_at(table, S, i_em, lam_c[k]); /* :324 */
-                            contribution[k] = contribution[k] * c;                                /* :326-327 */
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < NSETS; k += 1)
-                    {
-                        dst[k] = dst[k] + throughput[k] * contribution[k]; /* :461-462 */
-                        double reflectance = diffuse_pi[k] * s_a_in + 0.0;
-                        reflectance = (glossy[k] * s_spec) * s_a_in + reflectance;
-                        reflectance = reflectance * dir_pdf;         /* :468 */
-                        throughput[k] = throughput[k] * reflectance; /* :469 */
-                    }
+                    plastic_vertex(w1, dir_pdf, s_a_in, s_spec);
                     continue;
                 }
 
