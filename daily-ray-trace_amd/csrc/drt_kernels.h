@@ -683,6 +683,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
     bool exhausted = false; /* wave-uniform: no more work to draw */
     uint64_t pid = 0, rs = 1, hit_row = 0; /* hit_row: the path's row in the hit log, ordered (sample, pixel) */
     uint32_t depth = 0, shaded = 0;
+    uint32_t vis0_mask = 0;    /* bit v: light 0 is visible from shaded vertex v (< 8); header bits 24-31 */
     uint32_t plastic_mask = 0; /* bit v: shaded vertex v (< 16) has the two-lobe plastic list; header bits 48-63, read by the shade kernel's tail pass */
     V3 ro = v3(0, 0, 0), rd = v3(0, 0, 0);
     uint64_t *rec = nullptr, *hdr = nullptr;
@@ -763,6 +764,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
                 depth = 0;
                 shaded = 0;
                 plastic_mask = 0;
+                vis0_mask = 0;
                 uint64_t slot = q * (uint64_t)tp.batch + s_local;
                 rec = records + slot * (uint64_t)tp.path_words;
                 hdr = headers + slot * REC_HEADER_WORDS;
@@ -840,6 +842,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
                         V3 incoming = v_normalise(v_sub(light_position, ip.position));
                         EvalCoef e = eval_coefficients(sc, sv, ip, incoming);
                         lflags = e.flags | FLAG_VISIBLE;
+                        if (l == 0 && shaded < 8u) vis0_mask |= 1u << shaded;
                         double c = attenuation * (light_pdf);
                         lrec[1] = (uint64_t)__double_as_longlong(c);
                         store_coef(lrec + 2, e);
@@ -869,7 +872,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
             depth += 1;
             if (terminal || depth >= tp.max_depth)
             {
-                hdr[0] = (uint64_t)shaded | ((uint64_t)term << 16) | ((uint64_t)(term_spd & 0xFFFFu) << 32) | ((uint64_t)plastic_mask << 48);
+                hdr[0] = (uint64_t)shaded | ((uint64_t)term << 16) | ((uint64_t)(term_spd & 0xFFFFu) << 32) | ((uint64_t)plastic_mask << 48) | ((uint64_t)vis0_mask << 24);
                 alive = false;
             }
         }
@@ -1327,6 +1330,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
             const uint32_t term = (uint32_t)(hs >> 16) & 0xFFu;
             const uint32_t term_spd = (uint32_t)(hs >> 32) & 0xFFFFu;
             const uint32_t plastic_mask = (uint32_t)(hs >> 48); /* bit v: vertex v has the two-lobe plastic list */
+            const uint32_t vis0_mask = (uint32_t)(hs >> 24) & 0xFFu; /* bit v (< 8): light 0 visible from vertex v */
             const uint64_t *p_s = rbase + (uint64_t)s * sp.path_words;
             /* rotate the ring, then start the load for the sample SHADE_PREFETCH_DEPTH ahead */
 #pragma unroll
@@ -1386,6 +1390,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
                         }
                         for (uint32_t l = 0; l < sp.n_lights; l += 1) /* direct_light_contribution, :272-332 */
                         {
+                            if (l == 0 && v < 8u && !((vis0_mask >> v) & 1u)) continue; /* known from the header: not visible, nothing to read */
                             const uint32_t off = REC_VERTEX_WORDS + l * REC_LIGHT_WORDS;
                             uint64_t lw[4];
                             if (off + REC_LIGHT_WORDS <= 64 || v < n_fast)
