@@ -116,7 +116,8 @@ struct DevCamera
 /* Records of one pixel's samples are contiguous: path slot = pixel * batch + sample_in_batch.     */
 /*                                                                                                  */
 /*  path header (2 words, own array):                                                              */
-/*     w0 = n_shaded (bits 0-15) | term (16-23: 0 none/escape, 1 emissive hit) | emission SPD (32-47) */
+/*     w0 = n_shaded (bits 0-15) | term (16-23: 0 none/escape, 1 emissive hit) | light 0 visible from vertex v < 8 (24-31) |
+ *          emission SPD (32-47) | vertex v < 16 has the two-lobe plastic list (48-63)                                      */
 /*     w1 = vignette (double)                                                                      */
 /*  vertex fixed part (10 words):                                                                  */
 /*     w0 = BDSF list, 4 bits per entry (the material's bdsfs[] in order)                          */
