@@ -906,6 +906,7 @@ struct ShadeParams
     uint32_t n_lights, batch;
     uint32_t tail_first, tail_count; /* wavelengths [tail_first, tail_first + tail_count) go through the packed tail pass (0: none) */
     uint32_t chunk, sub_pixels;      /* pixels per group (= tail packing size when there is a tail); pixels per main-pass work item */
+    uint32_t light0_em_spd, pad2;         /* emission SPD row of light 0 (what every light block of light 0 says) */
     double  *tail_stage;                  /* [n_pix * batch][tail_count]: per-sample results of the tail pass (see the kernel) */
     uint32_t cmf_rw, cmf_x, cmf_y, cmf_z; /* XYZ film mode: SPD rows of the white table and the colour-matching functions */
     uint32_t tail_period_mains, pad1;  /* split queue with a tail: main-pass items between two tail items (<= main items per group) */
@@ -1389,6 +1390,27 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
                             diffuse_pi[k] = spd_at(table, S, i_diffuse, lam_c[k]);
                             glossy[k] = spd_at(table, S, i_glossy, lam_c[k]);
                         }
+                        if (sp.n_lights == 1u && v < 8u && v < n_fast)
+                        {
+                            /* one light, and the header already says whether it is visible: its three numbers, nothing else
+                             * (the emission row of light 0 is the same in every block: sp.light0_em_spd) */
+                            if ((vis0_mask >> v) & 1u)
+                            {
+                                const uint32_t off = REC_VERTEX_WORDS;
+                                const double c = word_as_double(readlane64(src, lane0 + off + 1));
+                                const double a_in = word_as_double(readlane64(src, lane0 + off + 2)), spec = word_as_double(readlane64(src, lane0 + off + 3));
+#pragma unroll
+                                for (int k = 0; k < NSETS; k += 1)
+                                {
+                                    double reflectance = diffuse_pi[k] * a_in + 0.0;
+                                    reflectance = (glossy[k] * spec) * a_in + reflectance;
+                                    contribution[k] = contribution[k] + reflectance;                                    /* :323 */
+                                    contribution[k] = contribution[k] * spd_at(table, S, sp.light0_em_spd, lam_c[k]); /* :324 */
+                                    contribution[k] = contribution[k] * c;                                              /* :326-327 */
+                                }
+                            }
+                        }
+                        else
                         for (uint32_t l = 0; l < sp.n_lights; l += 1) /* direct_light_contribution, :272-332 */
                         {
                             if (l == 0 && v < 8u && !((vis0_mask >> v) & 1u)) continue; /* known from the header: not visible, nothing to read */

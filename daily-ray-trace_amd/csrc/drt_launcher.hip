@@ -54,6 +54,7 @@ struct drt_context
     bool    xyz_mode = false;
     bool    own_film = false;
     uint64_t *d_records = nullptr, *d_headers = nullptr;
+    uint32_t  light0_em_spd = 0;      /* emission SPD row of the first light (0 when there is none) */
     double   *d_tail_stage = nullptr; /* [n_pix * batch][tail_count]: per-sample results of the shade kernel's tail pass */
     uint32_t  batch_spp = 1;
     uint32_t  vertex_words = 0, path_words = 0;
@@ -469,6 +470,7 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene)
     if ((rc = upload(ctx, lights, &d.lights))) return rc;
     if ((rc = upload(ctx, ltype, &d.light_type))) return rc;
     if ((rc = upload(ctx, lmat, &d.light_mat))) return rc;
+    ctx->light0_em_spd = n_lights ? ((uint32_t)mats[lmat[0]].emission_spd & 0xFFFFu) : 0u; /* what the trace kernel writes into light 0's blocks */
     if ((rc = upload(ctx, mats, &d.mats))) return rc;
     if ((rc = upload(ctx, spds, &d.spds))) return rc;
 
@@ -877,6 +879,7 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
         sp.tail_first = ctx->tail_first;
         sp.tail_count = ctx->tail_count;
         sp.tail_stage = ctx->d_tail_stage;
+        sp.light0_em_spd = ctx->light0_em_spd;
         sp.cmf_rw = ctx->cmf_rw; sp.cmf_x = ctx->cmf_x; sp.cmf_y = ctx->cmf_y; sp.cmf_z = ctx->cmf_z;
         sp.chunk = ctx->tail_count ? 64u / ctx->tail_count : SHADE_PIXEL_CHUNK;
         uint64_t groups = (ctx->n_pix + sp.chunk - 1) / sp.chunk;
