@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark of the MI355X render path.
 
 Metric (BASELINE.json): Mpaths/s (pixels*spp/s), Cornell 1024^2, depth 8 -- cornell_plane_light.scn at
-1024x1024, 256 spp, max depth 8 (BASELINE configs[1]); plus the HBM-roofline fraction of the dominant kernel.
+1024x1024, 256 spp, max depth 8 (BASELINE configs[1]); plus the roofline fraction of the dominant kernel.
 
 A "step" is one full render of that frame: every sample of every pixel through the trace and the shade+film
 kernels, with scene, SPD tables and film resident in HBM when the clock starts. With N > 1 GPUs the frame is
@@ -11,11 +11,12 @@ film (three buffers, one contiguous allocation) is gathered to rank 0 over RCCL 
 step ends when the whole frame is assembled on rank 0. Total work is fixed, so scaling is "strong".
 
   python bench.py --gpus 1 --steps 3 --warmup 1
+  python bench.py --gpus N --steps K --warmup W            (starts the N ranks itself, one child process per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel with the algorithmic byte model of
-SURVEY 8d (see DESIGN.md "Measurement"); `cpu_baseline` is the reference's own CPU path (oracle/_ref, when that
+Rank 0 prints ONE JSON line. `roofline` is the dominant kernel against the bound that holds for it -- f64 vector issue
+(see roofline() below and DESIGN.md "Measurement"), with the measured HBM traffic beside it; `cpu_baseline` is the reference's own CPU path (oracle/_ref, when that
 library travelled with the repo) or the CPU oracle port, timed on this host on a bounded sample.
 """
 import argparse
@@ -77,6 +78,101 @@ def cpu_baseline(bundle_loader, width, height, depth, seconds_target=12.0):
     return out
 
 
+VALU_PEAK_GCYCLES = 1024 * 2.4  # vector-issue cycles available per ns: 256 CUs x 4 SIMDs at the 2.4 GHz peak shader clock
+FP64_PEAK_TFLOPS = 78.6         # 1024 SIMDs x 16 f64 lanes per clock x 2 (FMA) x 2.4 GHz (MI355X_MICROARCH.md: half the 157.3 TF f32 vector rate)
+
+
+def roofline(dominant, kernel_ms, launches, paths_per_launch, model, workload, xyz):
+    """The `roofline` object of the JSON line, for the dominant kernel.
+
+    This path has no dense contraction (no MFMA) and keeps its spectra in registers, so neither the matrix peak nor the HBM
+    peak bounds it: what bounds it is the rate at which a SIMD issues f64 vector instructions. `achieved` is the kernel's
+    vector-pipe busy time per launch (SQ_ACTIVE_INST_VALU x 4 cycles, per path, from the committed rocprofv3 PMC profile of
+    this same workload: profiles/roofline.json, regenerated by tools/roofline_from_profiles.py) divided by the launch
+    duration measured HERE with HIP events on the launch stream; `peak` is every SIMD issuing every cycle at the peak clock.
+    `traffic` is the measured HBM bytes per launch from the same profile and `hbm_measured_frac` what that is of 8 TB/s.
+    SURVEY 8d's byte model (a design that streams path state through HBM) is reported under `algorithmic_model`, as a model:
+    this design does not move those bytes, so they are never divided by time into a bandwidth."""
+    avg_ms = {k: (kernel_ms[k] / launches if launches else 0.0) for k in kernel_ms}
+    out = {"bound": "fp64_valu", "kernel": "drt_%s_kernel" % dominant, "achieved": None, "peak": round(VALU_PEAK_GCYCLES, 1),
+           "unit": "G SIMD-cycles/s of vector issue", "frac": None, "traffic": None, "hbm_measured_frac": None,
+           "launch": {"paths": paths_per_launch, "avg_ms": round(avg_ms[dominant], 4), "count": launches}}
+    prof = None
+    ppath = os.path.join(REPO, "profiles", "roofline.json")
+    if os.path.exists(ppath) and not xyz:
+        try:
+            pj = json.load(open(ppath))
+            if pj.get("workload") == workload:
+                prof = pj
+        except Exception:
+            prof = None
+    if prof:
+        per_kernel = {}
+        for k, e in prof["kernels"].items():
+            sec = avg_ms.get(k, 0.0) * 1e-3
+            if sec <= 0:
+                continue
+            d = {"avg_launch_ms": round(avg_ms[k], 4)}
+            if "valu_busy_simd_cycles" in e:
+                d["valu_busy_Gcycles_per_s"] = round(e["valu_busy_simd_cycles"] * paths_per_launch / sec / 1e9, 1)
+                d["valu_busy_frac"] = round(d["valu_busy_Gcycles_per_s"] / VALU_PEAK_GCYCLES, 4)
+                d["valu_busy_frac_in_profile"] = e.get("valu_busy_frac")  # against the clock the chip actually held in the PMC pass
+            if "lane_efficiency" in e:
+                d["lane_efficiency"] = e["lane_efficiency"]
+            if "f64_flops" in e:
+                tf = e["f64_flops"] * paths_per_launch / sec / 1e12
+                d["fp64"] = {"achieved": round(tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_PEAK_TFLOPS, 4)}
+            if "hbm_bytes" in e:
+                d["hbm_bytes_per_launch"] = round(e["hbm_bytes"] * paths_per_launch)
+                d["hbm_GBs"] = round(e["hbm_bytes"] * paths_per_launch / sec / 1e9, 1)
+                d["hbm_measured_frac"] = round(d["hbm_GBs"] / HBM_PEAK_GBS, 4)
+            per_kernel[k] = d
+        dk = per_kernel.get(dominant, {})
+        out.update({"achieved": dk.get("valu_busy_Gcycles_per_s"), "frac": dk.get("valu_busy_frac"),
+                    "traffic": dk.get("hbm_bytes_per_launch"), "hbm_measured_frac": dk.get("hbm_measured_frac"),
+                    "lane_efficiency": dk.get("lane_efficiency"), "fp64": dk.get("fp64"), "per_kernel": per_kernel,
+                    "counters_from": "profiles/roofline.json <- %s" % prof.get("source", "")})
+    else:
+        out["note"] = "no committed PMC profile matches this workload (profiles/roofline.json): vector-issue and HBM fractions not reported"
+    out["algorithmic_model"] = {
+        "what": "SURVEY 8d byte model of a design that streams path state through HBM; a MODEL, not traffic -- this design keeps "
+                "throughput and radiance spectra in registers, so these bytes are not moved and are not a bandwidth",
+        "bytes_per_path": {k: round(v, 1) for k, v in model.items()},
+        "bytes_per_launch": round(model[dominant] * paths_per_launch),
+        "measured_traffic_over_model": (round(out["traffic"] / (model[dominant] * paths_per_launch), 4) if out["traffic"] else None)}
+    return out
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` from a plain shell: start the N ranks as fresh child processes (one per GPU, torch's own
+    launcher, rendezvous on 127.0.0.1) and relay rank 0's JSON line. This parent never imports torch or touches the GPU, so
+    nothing that has initialised HIP is ever exec'ed or forked; a rank that fails makes the whole call fail."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for line in child.stdout:
+        if line.startswith("{"):
+            lines.append(line.rstrip("\n"))
+        else:
+            sys.stderr.write(line)
+    rc = child.wait()
+    if rc != 0:
+        sys.stderr.write("bench.py: the %d-rank launch failed (exit code %d)\n" % (n, rc))
+        return rc
+    if len(lines) != 1:
+        sys.stderr.write("bench.py: expected one JSON line from rank 0, got %d\n" % len(lines))
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,6 +193,8 @@ def main():
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes needs dmabuf IPC on this driver
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     import torch
     import pydrt
     import drt_dist
@@ -105,8 +203,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d processes" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one process per GPU (or leave WORLD_SIZE unset and bench.py starts them itself)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if args.share_device:
@@ -250,21 +347,14 @@ def main():
         value = total_paths / elapsed / 1e6
         model = algorithmic_bytes(S, v_int, v_shade, xyz)
         dominant = "shade" if shade_ms >= trace_ms else "trace"
-        dom_ms = max(shade_ms, trace_ms)
         # per launch: paths per kernel launch and its average duration (launches = batches)
         paths_per_launch = batch_spp * block_pixels
         launches = max(1, round(paths_rank / max(paths_per_launch, 1)))
-        avg_launch_ms = dom_ms / launches
-        achieved = model[dominant] * paths_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "traffic.json")
-        if os.path.exists(tpath) and not xyz:
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == "cornell_plane_light %dx%d depth %d" % (W, H, args.depth):
-                    traffic = round(tj["hbm_bytes_per_path"][dominant] * paths_per_launch)
-            except Exception:
-                traffic = None
+        kernel_ms = {"trace": trace_ms, "shade": shade_ms}
+        roof = roofline(dominant, kernel_ms, launches, paths_per_launch, model,
+                        "cornell_plane_light %dx%d depth %d" % (W, H, args.depth), xyz)
+        roof.update({"kernel_ms_per_step": {"trace": round(trace_ms / args.steps, 3), "shade": round(shade_ms / args.steps, 3)},
+                     "v_int": round(v_int, 4), "v_shade": round(v_shade, 4)})
         out = {
             "metric": "Mpaths/s (pixels*spp/s) Cornell 1024^2 depth 8; achieved HBM GB/s % of peak" + (" [XYZ-only film: NOT the headline mode]" if xyz else ""),
             "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -276,17 +366,7 @@ def main():
                        "partition": ("whole frame on one GPU" if world == 1 and len(blocks) == 1 else
                                      "rows cyclic over %d rank(s) in %d row block(s); each block's film gathered to rank 0 while the next renders" % (world, len(blocks))),
                        "paths_per_step": W * H * args.spp},
-            "roofline": {"bound": "hbm", "kernel": "drt_%s_kernel" % dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "launch": {"paths": paths_per_launch, "avg_ms": round(avg_launch_ms, 4), "count": launches,
-                                                        "algorithmic_bytes": round(model[dominant] * paths_per_launch)},
-                         "algorithmic_bytes_per_path": {k: round(v, 1) for k, v in model.items()},
-                         "kernel_ms_per_step": {"trace": round(trace_ms / args.steps, 3), "shade": round(shade_ms / args.steps, 3)},
-                         "whole_path_GBs": round(model["path"] * (total_paths / elapsed) / 1e9, 1),
-                         "v_int": round(v_int, 4), "v_shade": round(v_shade, 4),
-                         "note": "achieved = SURVEY 8d algorithmic bytes of the dominant kernel / its HIP-event time on rank 0 (the model "
-                                 "assumes path state streamed through HBM; this design keeps it in registers, so frac can exceed 1: see traffic); "
-                                 "traffic = HBM bytes per launch of that kernel from the committed rocprofv3 PMC profile (profiles/traffic.json), when it matches"},
+            "roofline": roof,
         }
         if world > 1:
             out["gather_ms_per_step"] = round(gather_ms[0] / args.steps, 3)  # the part not hidden behind rendering

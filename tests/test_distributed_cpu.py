@@ -115,3 +115,24 @@ def test_rank_rows_cover_every_row_once():
                 assert (ys < height).all()
                 seen[ys] += 1
             assert (seen == 1).all()
+
+
+def test_bench_self_launch_reports_a_failing_rank():
+    """`python bench.py --gpus 2` from a plain shell starts its two ranks itself. Without a GPU every rank refuses to run
+    (no CPU fallback); the launcher must pass that on as a non-zero exit code and print no JSON line."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present: the ranks would run")
+    except ImportError:
+        pytest.skip("torch not importable")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device",
+                          "--size", "16", "--spp", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert "needs a GPU" in out.stderr and "2-rank launch failed" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

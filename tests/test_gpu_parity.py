@@ -524,6 +524,10 @@ def test_bench_two_rank_rehearsal_assembles_the_same_frame():
                      "--master-port", "29533", bench, "--gpus", "2", "--backend", "gloo", "--share-device", "--gather-blocks", "3"] + common)
     assert two["n_gpus"] == 2 and two["frame_checksum"] == one["frame_checksum"]
     assert two["config"]["paths_per_step"] == 96 * 96 * 6
+    # the same from a plain shell: `python bench.py --gpus 2` starts its ranks itself (no torch.distributed.run on the command line)
+    env.pop("WORLD_SIZE", None)
+    plain = last_json([sys.executable, bench, "--gpus", "2", "--backend", "gloo", "--share-device", "--gather-blocks", "3"] + common)
+    assert plain["n_gpus"] == 2 and plain["frame_checksum"] == one["frame_checksum"]
     # three ranks on an image whose rows do not divide evenly (ranks own 34, 33, 33 rows of 100), default block count
     common[1] = "100"
     one100 = last_json([sys.executable, bench] + common)
