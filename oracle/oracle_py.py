@@ -125,6 +125,26 @@ def oracle_film_to_xyz(bundle, pixels):
 
 
 # ------------------------------------------------------------------------------------------------
+class RefSpdInput(C.Structure):
+    _fields_ = [("method", C.c_uint32), ("has_scale_factor", C.c_uint32), ("scale_factor", C.c_double),
+                ("value", C.c_double * 3), ("csv", C.c_char * 64)]
+
+
+class RefMaterialInput(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("is_base_material", C.c_uint32), ("is_escape_material", C.c_uint32),
+                ("is_black_body", C.c_uint32), ("is_emissive", C.c_uint32), ("shininess", C.c_double),
+                ("roughness", C.c_double), ("spd", RefSpdInput * 6), ("num_bdsfs", C.c_uint32),
+                ("bdsfs", C.c_int32 * 16), ("dir_func", C.c_int32)]
+
+
+class RefSurfaceInput(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("material_name", C.c_char * 32), ("type", C.c_uint32), ("pad", C.c_uint32),
+                ("position", C.c_double * 3), ("radius", C.c_double), ("normal", C.c_double * 3),
+                ("u", C.c_double * 3), ("v", C.c_double * 3)]
+
+
+SPD_METHOD_NONE, SPD_METHOD_RGB, SPD_METHOD_CSV, SPD_METHOD_BLACKBODY, SPD_METHOD_CONST = range(5)  # src/read_scene.h:15-23
+
 _ref = None
 
 
@@ -182,6 +202,18 @@ def ref_lib():
         L.ref_sample_scene.argtypes = [Cm, P, C.c_uint32, C.c_uint32, C.c_uint32, f64p, f64p]
         L.ref_trace_hits.argtypes = [Cm, P, C.c_uint32, C.c_uint32, C.c_uint32, i32p, f64p]
         L.ref_render_tile.argtypes = [Cm, P, f64p, f64p, f64p]
+        # the reference's own parser and CSV resampling (harness version 2)
+        u32p = C.POINTER(C.c_uint32)
+        L.ref_parse_scene.argtypes = [C.c_char_p, C.c_uint32, u32p, u32p]
+        L.ref_parsed_camera.argtypes = [f64p]
+        L.ref_parsed_material.argtypes = [C.c_uint32, C.POINTER(RefMaterialInput)]
+        L.ref_parsed_surface.argtypes = [C.c_uint32, C.POINTER(RefSurfaceInput)]
+        L.ref_parse_config.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.ref_sizeof_config.restype = C.c_uint32
+        L.ref_csv_to_spectrum.argtypes = [C.c_char_p, f64p]
+        L.ref_spectrum_normalise.argtypes = [f64p]
+        L.ref_spectral_mul_by_scalar.argtypes = [f64p, C.c_double]
+        L.ref_const_spectrum.argtypes = [f64p, C.c_double]
         _ref = L
     return _ref
 
@@ -223,3 +255,36 @@ def ref_trace_hits(bundle, params):
                                    spec_real[k].ctypes.data_as(f64p), C.byref(filt))
                 k += 1
     return hits, spec_replay, spec_real
+
+
+def ref_parse_scene(text):
+    """The reference's own parse_scene (src/read_scene.c) on a .scn text. Returns (rc, camera[11], materials, surfaces);
+    rc != 0 is what parse_error()'s exit() was called with. The reference's arrays hold 16 materials / 16 surfaces
+    with no bounds check (src/read_scene.h:85-86), so the caller must not pass larger scenes."""
+    L = ref_lib()
+    b = text.encode() if isinstance(text, str) else text
+    nm, ns = C.c_uint32(), C.c_uint32()
+    rc = L.ref_parse_scene(b, len(b), C.byref(nm), C.byref(ns))
+    cam = np.zeros(11)
+    L.ref_parsed_camera(_ptr(cam))
+    mats, surfs = [], []
+    if rc == 0:
+        for i in range(min(nm.value, 16)):
+            m = RefMaterialInput()
+            L.ref_parsed_material(i, C.byref(m))
+            mats.append(m)
+        for i in range(min(ns.value, 16)):
+            su = RefSurfaceInput()
+            L.ref_parsed_surface(i, C.byref(su))
+            surfs.append(su)
+    return rc, cam, mats, surfs
+
+
+def ref_parse_config(text):
+    """The reference's parse_config into its own 1136-byte config_arguments; returns (rc, bytes)."""
+    L = ref_lib()
+    b = text.encode() if isinstance(text, str) else text
+    n = L.ref_sizeof_config()
+    buf = C.create_string_buffer(n)
+    rc = L.ref_parse_config(b, len(b), buf, n)
+    return rc, buf.raw

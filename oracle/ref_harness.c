@@ -9,12 +9,23 @@
  *                      Win32 platform layer, the .scn parser and the render driver
  *                      (<Windows.h>, win32_platform.h/.c, read_scene.c, daily_ray_trace.c);
  *   drt_ref_path.inc = src/daily_ray_trace.c lines 49-77 (init_camera), 213-479 (bdsf ..
- *                      cast_ray) and 545-618 (sample_pixel_point, sample_scene), verbatim.
+ *                      cast_ray) and 545-618 (sample_pixel_point, sample_scene), verbatim;
+ *   drt_ref_pixel_body.inc = src/daily_ray_trace.c lines 729-743, verbatim: the body of
+ *                      render_image's pixel loop (sample_scene call, accumulation, running
+ *                      mean / variance), compiled inside ref_render_tile's loop below;
+ *   drt_ref_parser.inc = src/read_scene.c lines 1-796 (tokenizer, parse_scene, parse_config),
+ *                      verbatim but for the spelling of `#include "Keywords.h"` (the file is
+ *                      keywords.h; Linux is case-sensitive);
+ *   drt_ref_csv_body.inc = src/read_scene.c lines 812-840 and 843-end: the body of
+ *                      load_csv_file_to_spectrum after its Win32 file read, without the
+ *                      unalloc() call (the buffer is this harness's own).
  * Every other reference file used (types.h utils.[ch] spectrum.[ch] geometry.[ch] rng.[ch]
  * bdsf.[ch] bdsf_list.h read_scene.h) is included whole, unmodified, straight from the tree.
  * No stand-in is written for any header, library or function the image lacks: the platform
- * layer, the parser and render_image are simply not part of this build (their callers are
- * dropped by --gc-sections), and scene data arrives through the boundary structs instead.
+ * layer, init_scene / init_spd (they need its alloc and file calls) and render_image's set-up
+ * are simply not part of this build (their callers are dropped by --gc-sections), and scene
+ * data arrives through the boundary structs instead. printf and exit are macro-renamed around
+ * the parser (it is chatty, and its parse_error() ends the process: here it ends the parse).
  *
  * rand()/srand() are macro-renamed to the build's per-path xorshift64;
  * glibc's RAND_MAX (2^31-1) is what rng() divides by.
@@ -49,6 +60,26 @@ static void drt_probe_srand(unsigned seed) { g_ref_rng_state = seed ? seed : 1; 
 
 #undef rand
 #undef srand
+
+/* ---- the reference's tokenizer + parse_scene + parse_config, and its CSV resampling -------- */
+#include <setjmp.h>
+static jmp_buf g_parse_jmp;
+static int g_parse_active = 0;
+static void ref_parse_exit(int code)
+{
+    if (g_parse_active) longjmp(g_parse_jmp, code ? code : 1);
+    abort();
+}
+static int ref_quiet_printf(const char *fmt, ...) { (void)fmt; return 0; }
+#define printf ref_quiet_printf
+#define exit ref_parse_exit
+#include "drt_ref_parser.inc"
+static u32 ref_csv_body(spectrum dst, char *csv_file_buffer, u32 csv_file_size)
+{
+    (void)csv_file_size;
+#include "drt_ref_csv_body.inc"
+#undef printf
+#undef exit
 
 #include "../include/drt_hip.h"
 
@@ -410,48 +441,190 @@ REF_API int ref_trace_hits(const drt_camera *c, const drt_params *p, uint32_t x,
     return scans;
 }
 
-/* The pixel loop of render_image (src/daily_ray_trace.c:710-745) over a tile, with the per-path
- * seeding; film buffers are accumulated into with the reference's spectral ops in its order. */
+/* The pixel loop of render_image (src/daily_ray_trace.c:710-745) over a tile. The loop's BODY is the reference's own text
+ * (lines 729-743, compiled in place from drt_ref_pixel_body.inc); this function only supplies the variables that body
+ * names -- with the reference's names and types -- and seeds the per-path generator before it. */
 REF_API void ref_render_tile(const drt_camera *c, const drt_params *p, double *pixels, double *avgs, double *vars)
 {
-    camera_data cam = cam_in(c);
+    camera_data camera = cam_in(c);
+    scene_data scene = g_scene; /* shallow copy: the body says &scene */
     uint32_t S = number_of_spectrum_samples;
-    f64 *cbuf = (f64 *)calloc(S + 1, sizeof(f64));
-    spectrum contribution; contribution.samples = cbuf;
-    f64 *filter = &cbuf[S];
-    spectrum tmp0 = alloc_spd(), tmp1 = alloc_spd();
+    f64 *contribution_buffer = (f64 *)calloc(S + 1, sizeof(f64));
+    spectrum contribution; contribution.samples = contribution_buffer;
+    f64 *filter = &contribution_buffer[number_of_spectrum_samples];
+    spectrum tmp_0_spd = alloc_spd(), tmp_1_spd = alloc_spd();
+    u32 max_cast_depth = p->max_depth;
+    config_arguments config_storage;
+    config_arguments *config = &config_storage;
+    config->pixel_scheme = (film_sample_scheme)p->pixel_scheme;
     uint32_t stride = p->row_stride ? p->row_stride : 1;
     for (uint32_t s = 0; s < p->spp; s += 1)
     {
-        uint32_t sample = p->first_sample + s;
+        u32 sample = p->first_sample + s;
         for (uint32_t j = 0; j < p->tile_h; j += 1)
         {
-            uint32_t y = p->y0 + j * stride;
+            u32 y = p->y0 + j * stride;
             for (uint32_t i = 0; i < p->tile_w; i += 1)
             {
-                uint32_t x = p->x0 + i;
+                u32 x = p->x0 + i;
                 uint64_t off = (uint64_t)j * p->tile_w + i;
-                spectrum dp, da, dv;
-                dp.samples = pixels + off * (S + 1);
-                da.samples = avgs + off * S;
-                dv.samples = vars + off * S;
+                f64 *dst_pixel = pixels + off * (S + 1);
+                spectrum dst_pixel_spd, dst_pixel_avg, dst_pixel_var;
+                dst_pixel_spd.samples = dst_pixel;
+                dst_pixel_avg.samples = avgs + off * S;
+                dst_pixel_var.samples = vars + off * S;
                 ref_seed_path(p->seed + (((uint64_t)sample * p->height + y) * (uint64_t)p->width + x));
-                sample_scene(contribution, filter, x, y, &g_scene, &cam, p->max_depth, (film_sample_scheme)p->pixel_scheme);
-                spectral_sum(dp, dp, contribution);
-                dp.samples[S] += *filter;
-                copy_spectrum(tmp0, da);
-                spectral_sub(tmp0, contribution, tmp0);
-                copy_spectrum(tmp1, tmp0);
-                spectral_div_by_scalar(tmp0, tmp0, (f64)(sample + 1));
-                spectral_sum(da, da, tmp0);
-                spectral_sub(tmp0, contribution, da);
-                spectral_mul_by_spectrum(tmp0, tmp1, tmp0);
-                spectral_sum(dv, dv, tmp0);
+#include "drt_ref_pixel_body.inc"
             }
         }
     }
-    free_spd(tmp1); free_spd(tmp0);
-    free(cbuf);
+    free_spd(tmp_1_spd); free_spd(tmp_0_spd);
+    free(contribution_buffer);
 }
 
-REF_API int ref_version(void) { return 1; }
+/* ---- parser exports --------------------------------------------------------------------------- */
+static camera_input_data g_parsed_camera;
+static scene_input_data  g_parsed_scene;
+
+/* parse_scene on a copy of `text`. Returns 0, or the code parse_error() would have ended the process with
+ * (its exit(-1) arrives here as 255 / -1 -> nonzero). Counts come back through the pointers. */
+REF_API int ref_parse_scene(const char *text, uint32_t size, uint32_t *num_materials, uint32_t *num_surfaces)
+{
+    char *copy = (char *)calloc((size_t)size + 2, 1);
+    memcpy(copy, text, size);
+    memset(&g_parsed_camera, 0, sizeof(g_parsed_camera));
+    memset(&g_parsed_scene, 0, sizeof(g_parsed_scene));
+    memset(&tokeniser, 0, sizeof(tokeniser));
+    int rc = 0;
+    g_parse_active = 1;
+    if ((rc = setjmp(g_parse_jmp)) == 0) parse_scene(copy, size, &g_parsed_camera, &g_parsed_scene);
+    g_parse_active = 0;
+    free(copy);
+    if (num_materials) *num_materials = g_parsed_scene.num_scene_materials;
+    if (num_surfaces) *num_surfaces = g_parsed_scene.num_surfaces;
+    return rc;
+}
+/* target, position, roll, fov, fdepth, flength, aperture */
+REF_API void ref_parsed_camera(double out[11])
+{
+    v3_out(g_parsed_camera.target, out); v3_out(g_parsed_camera.position, out + 3);
+    out[6] = g_parsed_camera.roll; out[7] = g_parsed_camera.fov; out[8] = g_parsed_camera.fdepth;
+    out[9] = g_parsed_camera.flength; out[10] = g_parsed_camera.aperture;
+}
+typedef struct
+{
+    uint32_t method, has_scale_factor;
+    double   scale_factor;
+    double   value[3]; /* rgb; or value[0] = blackbody temperature / constant */
+    char     csv[64];
+} ref_spd_input;
+typedef struct
+{
+    char     name[32];
+    uint32_t is_base_material, is_escape_material, is_black_body, is_emissive;
+    double   shininess, roughness;
+    ref_spd_input spd[6]; /* emission, diffuse, glossy, mirror, refract, extinct */
+    uint32_t num_bdsfs;
+    int32_t  bdsfs[16]; /* index into bdsf_list, -1 when the pointer is none of them */
+    int32_t  dir_func;
+} ref_material_input;
+typedef struct
+{
+    char     name[32], material_name[32];
+    uint32_t type, pad;
+    double   position[3], radius, normal[3], u[3], v[3];
+} ref_surface_input;
+
+static void spd_input_out(const spd_input_data *in, ref_spd_input *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->method = (uint32_t)in->method;
+    o->has_scale_factor = in->has_scale_factor;
+    o->scale_factor = in->scale_factor;
+    switch (in->method)
+    {
+        case SPD_METHOD_RGB: o->value[0] = in->rgb.r; o->value[1] = in->rgb.g; o->value[2] = in->rgb.b; break;
+        case SPD_METHOD_CSV: memcpy(o->csv, in->csv, 64); break;
+        case SPD_METHOD_BLACKBODY: o->value[0] = in->blackbody_temp; break;
+        case SPD_METHOD_CONST: o->value[0] = in->constant; break;
+        default: break;
+    }
+}
+REF_API int ref_parsed_material(uint32_t i, ref_material_input *o)
+{
+    if (i >= 16) return -1;
+    const material_input_data *m = &g_parsed_scene.scene_materials[i];
+    memset(o, 0, sizeof(*o));
+    memcpy(o->name, m->name, 32);
+    o->is_base_material = m->is_base_material; o->is_escape_material = m->is_escape_material;
+    o->is_black_body = m->is_black_body; o->is_emissive = m->is_emissive;
+    o->shininess = m->shininess; o->roughness = m->roughness;
+    spd_input_out(&m->emission_input, &o->spd[0]); spd_input_out(&m->diffuse_input, &o->spd[1]);
+    spd_input_out(&m->glossy_input, &o->spd[2]); spd_input_out(&m->mirror_input, &o->spd[3]);
+    spd_input_out(&m->refract_input, &o->spd[4]); spd_input_out(&m->extinct_input, &o->spd[5]);
+    o->num_bdsfs = m->num_bdsfs;
+    for (uint32_t j = 0; j < 16; j += 1)
+    {
+        o->bdsfs[j] = -1;
+        for (uint32_t k = 0; k < num_bdsfs_defined; k += 1) if (m->bdsfs[j] == bdsf_list[k]) o->bdsfs[j] = (int32_t)k;
+    }
+    o->dir_func = -1;
+    for (uint32_t k = 0; k < num_dir_funcs_defined; k += 1) if (m->sample_direction_function == dir_func_list[k]) o->dir_func = (int32_t)k;
+    return 0;
+}
+REF_API int ref_parsed_surface(uint32_t i, ref_surface_input *o)
+{
+    if (i >= 16) return -1;
+    const surface_input_data *s = &g_parsed_scene.surfaces[i];
+    memset(o, 0, sizeof(*o));
+    memcpy(o->name, s->name, 32);
+    memcpy(o->material_name, s->material_name, 32);
+    o->type = (uint32_t)s->type;
+    v3_out(s->position, o->position);
+    if (s->type == GEO_TYPE_SPHERE) o->radius = s->radius;
+    else
+    {
+        v3_out(s->normal, o->normal); v3_out(s->u, o->u); v3_out(s->v, o->v);
+    }
+    return 0;
+}
+/* parse_config into the reference's own 1136-byte config_arguments (the caller's buffer is zeroed first). */
+REF_API int ref_parse_config(const char *text, uint32_t size, void *config_out, uint32_t config_size)
+{
+    if (config_size != sizeof(config_arguments)) return -2;
+    char *copy = (char *)calloc((size_t)size + 2, 1);
+    memcpy(copy, text, size);
+    memset(config_out, 0, sizeof(config_arguments));
+    memset(&tokeniser, 0, sizeof(tokeniser));
+    int rc = 0;
+    g_parse_active = 1;
+    if ((rc = setjmp(g_parse_jmp)) == 0) parse_config(copy, size, (config_arguments *)config_out);
+    g_parse_active = 0;
+    free(copy);
+    return rc;
+}
+REF_API uint32_t ref_sizeof_config(void) { return (uint32_t)sizeof(config_arguments); }
+
+/* The reference's CSV resampling (the body of load_csv_file_to_spectrum, src/read_scene.c:812-872) on the bytes of `path`,
+ * read here with stdio into a zero-filled buffer one byte larger than the file, as the reference's alloc() + read leave it.
+ * The grid is the one ref_set_grid() set. Returns 0 when the file cannot be read. */
+REF_API int ref_csv_to_spectrum(const char *path, double *dst)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return 0;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    char *buf = (char *)calloc((size_t)n + 4, 1);
+    if (fread(buf, 1, (size_t)n, f) != (size_t)n) { fclose(f); free(buf); return 0; }
+    fclose(f);
+    spectrum s; s.samples = dst;
+    u32 ok = ref_csv_body(s, buf, (u32)n + 1);
+    free(buf);
+    return (int)ok;
+}
+REF_API void ref_spectrum_normalise(double *spd) { spectrum s; s.samples = spd; spectrum_normalise(s); }
+REF_API void ref_spectral_mul_by_scalar(double *spd, double f) { spectrum s; s.samples = spd; spectral_mul_by_scalar(s, s, f); }
+REF_API void ref_const_spectrum(double *spd, double f) { spectrum s; s.samples = spd; const_spectrum(s, f); }
+
+REF_API int ref_version(void) { return 2; }
