@@ -1689,3 +1689,80 @@ __global__ void drt_selftest_kernel(int op, const double *a, const double *b, do
         default: out[i] = 0.0; break;
     }
 }
+
+/* Device-function self-test (see drt_selftest_unit in include/drt_hip.h): one record per thread, `in_stride` doubles in,
+ * `out_stride` doubles out, each function called exactly as the trace / shade kernels call it. */
+enum
+{
+    DRT_UNIT_LINE_SPHERE = 0,   /* in: o[3] d[3] c[3] r                    out: t                         src/geometry.c:123-146 */
+    DRT_UNIT_LINE_PLANE,        /* in: o[3] d[3] p[3] n[3] u[3] v[3]       out: t                         src/geometry.c:157-182 */
+    DRT_UNIT_REFLECT,           /* in: v[3] n[3]                           out: r[3]                      src/geometry.c:85-90   */
+    DRT_UNIT_TRANSMIT,          /* in: v[3] n[3] ir tr                     out: t[3]                      src/geometry.c:92-106  */
+    DRT_UNIT_ROTATION_BETWEEN,  /* in: v[3] w[3]                           out: m[9] (columns)            src/geometry.c:263-295 */
+    DRT_UNIT_SAMPLE_SPHERE,     /* in: rng state (u64 bits)                out: p[3], state after (bits)  src/rng.c:14-23        */
+    DRT_UNIT_SAMPLE_DISC,       /* in: rng state (u64 bits)                out: p[3], state after (bits)  src/rng.c:25-51        */
+    DRT_UNIT_GGX,               /* in: sn[3] mn[3] roughness               out: D                         src/bdsf.c:3-20        */
+    DRT_UNIT_GGX_ATT,           /* in: v[3] sn[3] mn[3] roughness          out: D * G1                    src/bdsf.c:22-42       */
+    DRT_UNIT_FS_DIELECTRIC,     /* in: ir tr cos                           out: R                         src/bdsf.c:44-67       */
+    DRT_UNIT_FS_CONDUCTOR,      /* in: ir tr te cos                        out: R                         src/bdsf.c:78-101      */
+    DRT_UNIT_SEED_AND_DRAW,     /* in: path key (u64 bits)                 out: state (bits), first rng() src/rng.c:1-12, SURVEY 8a-R */
+    DRT_UNIT_COUNT
+};
+
+__global__ void drt_unit_kernel(int func, const double *__restrict__ in, uint32_t in_stride, double *__restrict__ out,
+                                uint32_t out_stride, uint64_t n)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *a = in + i * in_stride;
+    double *o = out + i * out_stride;
+    auto V = [&](int k) { return v3(a[k], a[k + 1], a[k + 2]); };
+    auto put = [&](int k, V3 v) { o[k] = v.x; o[k + 1] = v.y; o[k + 2] = v.z; };
+    switch (func)
+    {
+        case DRT_UNIT_LINE_SPHERE: o[0] = line_sphere(V(0), V(3), V(6), a[9]); break;
+        case DRT_UNIT_LINE_PLANE:
+        {
+            /* the per-plane constants as build_device_scene() derives them from the edge vectors */
+            V3 u = V(12), v = V(15);
+            double ul = v_length(u), vl = v_length(v);
+            o[0] = line_plane(V(0), V(3), V(6), V(9), v_div(u, ul), v_div(v, vl), ul, vl);
+            break;
+        }
+        case DRT_UNIT_REFLECT: put(0, v_reflect(V(0), V(3))); break;
+        case DRT_UNIT_TRANSMIT: put(0, v_transmit(V(0), V(3), a[6], a[7])); break;
+        case DRT_UNIT_ROTATION_BETWEEN:
+        {
+            M33 m = rotation_between(V(0), V(3));
+            put(0, m.c[0]); put(3, m.c[1]); put(6, m.c[2]);
+            break;
+        }
+        case DRT_UNIT_SAMPLE_SPHERE:
+        case DRT_UNIT_SAMPLE_DISC:
+        {
+            uint64_t rs = (uint64_t)__double_as_longlong(a[0]);
+            uint32_t draws = 0;
+            put(0, func == DRT_UNIT_SAMPLE_SPHERE ? uniform_sample_sphere(rs, draws) : uniform_sample_disc(rs, draws));
+            o[3] = __longlong_as_double((long long)rs);
+            break;
+        }
+        case DRT_UNIT_GGX: o[0] = ggx(V(0), V(3), a[6]); break;
+        case DRT_UNIT_GGX_ATT: o[0] = ggx_att(V(0), V(3), V(6), a[9]); break;
+        case DRT_UNIT_FS_DIELECTRIC: o[0] = dielectric_reflectance(a[0], a[1], a[2], 1.0 - a[2] * a[2]); break; /* as the shade kernel calls it */
+        case DRT_UNIT_FS_CONDUCTOR:
+        {
+            double c2 = a[3] * a[3];
+            o[0] = conductor_reflectance(a[0], a[1], a[2], a[3], c2, 1.0 - c2);
+            break;
+        }
+        case DRT_UNIT_SEED_AND_DRAW:
+        {
+            uint64_t rs = drt_splitmix64((uint64_t)__double_as_longlong(a[0]));
+            uint32_t draws = 0;
+            o[0] = __longlong_as_double((long long)rs);
+            o[1] = drt_rng(rs, draws);
+            break;
+        }
+        default: break;
+    }
+}

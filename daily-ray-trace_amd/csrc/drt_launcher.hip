@@ -639,10 +639,18 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     size_t film_bytes = ctx->xyz_mode ? (size_t)ctx->n_pix * XYZ_FILM_WORDS * 8 : (size_t)ctx->n_pix * (3 * (size_t)S + 1) * 8;
-    while (batch > 1 && (size_t)ctx->n_pix * batch * ctx->path_words * 8 + film_bytes > free_b / 2) batch /= 2;
+    /* per path slot: the vertex records, the header, and the tail pass's staged results (when S leaves a tail) */
+    {
+        uint32_t sets = 0, tf = 0, tc = 0;
+        shade_sets(S, &sets, &tf, &tc);
+        ctx->tail_count = tc;
+    }
+    const size_t slot_bytes = (size_t)ctx->path_words * 8 + REC_HEADER_WORDS * 8 + (size_t)ctx->tail_count * 8;
+    while (batch > 1 && (size_t)ctx->n_pix * batch * slot_bytes + film_bytes > free_b / 2) batch /= 2;
     ctx->batch_spp = batch;
     size_t rec_bytes = (size_t)ctx->n_pix * batch * ctx->path_words * 8;
-    if (rec_bytes + film_bytes > free_b) return fail(-3, "not enough device memory: need %zu bytes", rec_bytes + film_bytes);
+    if ((size_t)ctx->n_pix * batch * slot_bytes + film_bytes > free_b)
+        return fail(-3, "not enough device memory: need %zu bytes", (size_t)ctx->n_pix * batch * slot_bytes + film_bytes);
     HIP_TRY(hipMalloc((void **)&ctx->d_records, rec_bytes));
     HIP_TRY(hipMalloc((void **)&ctx->d_headers, (size_t)ctx->n_pix * batch * REC_HEADER_WORDS * 8));
 
@@ -1299,6 +1307,32 @@ extern "C" int drt_selftest_arith(int device, int op, const double *a, const dou
     HIP_TRY(hipMemcpy(out, dout, out_n * 8, hipMemcpyDeviceToHost));
     (void)hipFree(da);
     (void)hipFree(db);
+    (void)hipFree(dout);
+    return 0;
+}
+
+extern "C" int drt_selftest_unit(int device, int func, const double *in, uint32_t in_stride, double *out, uint32_t out_stride, uint64_t n)
+{
+    g_last_error.clear();
+    if (func < 0 || func >= DRT_UNIT_COUNT) return fail(-1, "unknown unit function %d", func);
+    if (!in || !out || in_stride == 0 || out_stride == 0) return fail(-1, "null argument");
+    /* what each function reads and writes per record: a caller with narrower records would make the kernel read past its buffers */
+    static const uint32_t need_in[DRT_UNIT_COUNT] = {10, 18, 6, 8, 6, 1, 1, 7, 10, 3, 4, 1};
+    static const uint32_t need_out[DRT_UNIT_COUNT] = {1, 1, 3, 3, 9, 4, 4, 1, 1, 1, 1, 2};
+    if (in_stride < need_in[func] || out_stride < need_out[func])
+        return fail(-1, "unit function %d needs %u doubles in and %u out per record", func, need_in[func], need_out[func]);
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(device));
+    double *din = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void **)&din, n * in_stride * 8));
+    HIP_TRY(hipMalloc((void **)&dout, n * out_stride * 8));
+    HIP_TRY(hipMemcpy(din, in, n * in_stride * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dout, 0, n * out_stride * 8));
+    hipLaunchKernelGGL(drt_unit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, func, din, in_stride, dout, out_stride, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, n * out_stride * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(din);
     (void)hipFree(dout);
     return 0;
 }

@@ -151,6 +151,18 @@ int drt_host_write_spd(const char *path, u32 width, u32 height, u32 num_wl, u32 
 /* Reads a .spd; *pixels is malloc'ed. Returns 0 on success. */
 int drt_host_read_spd(const char *path, spd_file_header *header, f64 **pixels);
 
+/* The outputs of render_image() as one crash-safe set (host/drt_checkpoint.c): the three .spd files, with
+ * with_raw_variance also <variance_spd>.raw and the manifest <output_spd>.ckpt a resumed run needs. Returns 0 on success. */
+int drt_host_write_outputs(const config_arguments *config, u32 width, u32 height, u32 S, f64 min_wl, f64 interval,
+                           const f64 *dst_pixels, const f64 *dst_avgs, const f64 *dst_vars, int with_raw_variance,
+                           u32 samples_done, u64 seed);
+/* Loads a checkpointed set into the (caller-allocated, full-frame) film buffers if, and only if, manifest, headers, file
+ * sizes, filter sums and means all agree with each other and with the job; returns 0 and the samples held, or nonzero
+ * (buffers then hold garbage: clear them) with the reason in drt_host_checkpoint_error(). */
+int drt_host_load_checkpoint(const config_arguments *config, u32 width, u32 height, u32 S, u64 seed, f64 *dst_pixels,
+                             f64 *dst_avgs, f64 *dst_vars, u32 *samples_done);
+const char *drt_host_checkpoint_error(void);
+
 /* .spd -> BMP post-process (spd_file_to_bmp, src/win32_main.c:115-121). cmf: [4][S] rows rw, x, y, z. */
 void drt_host_spectrum_to_rgb(const f64 *cmf, u32 S, f64 interval, const f64 *spd, f64 rgb[3]);
 int  drt_host_write_bmp(const char *path, u32 width, u32 height, const f64 *rgb);

@@ -21,31 +21,6 @@ static f64 now_ms(void)
     return (f64)ts.tv_sec * 1000.0 + (f64)ts.tv_nsec * 1e-6;
 }
 
-/* The three .spd outputs (src/daily_ray_trace.c:758-770): sum+filter, mean, and the variance max-normalised per
- * pixel (:766-769, on a copy so the accumulators stay usable); optionally the raw variance for a later resume. */
-static int write_outputs(const config_arguments *config, const drt_scene *scene, u32 width, u32 height, const f64 *dst_pixels,
-                         const f64 *dst_avgs, const f64 *dst_vars, const char *raw_var_path)
-{
-    u32 S = scene->num_wavelengths;
-    u64 num_pixels = (u64)width * height;
-    f64 *norm = (f64 *)malloc(num_pixels * S * sizeof(f64));
-    if (!norm) return -1;
-    for (u64 px = 0; px < num_pixels; px += 1)
-    {
-        const f64 *v = dst_vars + px * S;
-        f64 *o = norm + px * S;
-        f64 highest = 0.0;
-        for (u32 i = 0; i < S; i += 1) if (v[i] > highest) highest = v[i];
-        for (u32 i = 0; i < S; i += 1) o[i] = v[i] / highest;
-    }
-    int w0 = drt_host_write_spd(config->output_spd, width, height, S, 1, scene->min_wavelength, scene->wavelength_interval, dst_pixels);
-    int w1 = drt_host_write_spd(config->variance_spd, width, height, S, 0, scene->min_wavelength, scene->wavelength_interval, norm);
-    int w2 = drt_host_write_spd(config->average_spd, width, height, S, 0, scene->min_wavelength, scene->wavelength_interval, dst_avgs);
-    int w3 = raw_var_path ? drt_host_write_spd(raw_var_path, width, height, S, 0, scene->min_wavelength, scene->wavelength_interval, dst_vars) : 0;
-    free(norm);
-    return (w0 || w1 || w2 || w3) ? -1 : 0;
-}
-
 int render_image_ex(config_arguments *config, const drt_host_options *opt, drt_stats *stats_out)
 {
     u32 width = config->output_width, height = config->output_height;
@@ -107,24 +82,22 @@ int render_image_ex(config_arguments *config, const drt_host_options *opt, drt_s
     drt_stats stats;
     memset(&stats, 0, sizeof(stats));
     u32 done = 0;
-    char raw_var_path[96];
-    snprintf(raw_var_path, sizeof(raw_var_path), "%s.raw", config->variance_spd);
+    const u64 seed = p.seed;
     if (opt && opt->resume)
     {
-        spd_file_header h0, h1, h2;
-        f64 *p0 = NULL, *p1 = NULL, *p2 = NULL;
-        if (drt_host_read_spd(config->output_spd, &h0, &p0) == 0 && drt_host_read_spd(config->average_spd, &h1, &p1) == 0 &&
-            drt_host_read_spd(raw_var_path, &h2, &p2) == 0 && h0.width_in_pixels == width && h0.height_in_pixels == height &&
-            h0.number_of_wavelengths == S && h0.has_filter_values && h1.number_of_wavelengths == S && h2.number_of_wavelengths == S)
+        /* host/drt_checkpoint.c: accepted only when manifest, headers, sizes, filter sums and means agree with the job */
+        if (drt_host_load_checkpoint(config, width, height, S, seed, dst_pixels, dst_avgs, dst_vars, &done) == 0)
         {
-            memcpy(dst_pixels, p0, num_pixels * (S + 1) * sizeof(f64));
-            memcpy(dst_avgs, p1, num_pixels * S * sizeof(f64));
-            memcpy(dst_vars, p2, num_pixels * S * sizeof(f64));
-            done = (u32)dst_pixels[S]; /* filter sum of pixel 0 = samples accumulated so far (filter value is 1) */
             if (!(opt && opt->quiet)) printf("Resuming after %u samples\n", done);
         }
-        else fprintf(stderr, "render_image: nothing to resume from, starting at sample 0\n");
-        free(p0); free(p1); free(p2);
+        else
+        {
+            fprintf(stderr, "render_image: not resuming (%s), starting at sample 0\n", drt_host_checkpoint_error());
+            memset(dst_pixels, 0, num_pixels * (S + 1) * sizeof(f64));
+            memset(dst_avgs, 0, num_pixels * S * sizeof(f64));
+            memset(dst_vars, 0, num_pixels * S * sizeof(f64));
+            done = 0;
+        }
     }
     f64 t0 = now_ms();
     int rc = 0;
@@ -147,7 +120,8 @@ int render_image_ex(config_arguments *config, const drt_host_options *opt, drt_s
         if (done < p.spp) /* a checkpoint: the final write below uses the same code */
         {
             if ((rc = drt_group_read_film(ctx, dst_pixels, dst_avgs, dst_vars))) break;
-            if (write_outputs(config, scene, width, height, dst_pixels, dst_avgs, dst_vars, raw_var_path)) fprintf(stderr, "render_image: checkpoint write failed\n");
+            if (drt_host_write_outputs(config, width, height, S, scene->min_wavelength, scene->wavelength_interval, dst_pixels, dst_avgs, dst_vars, 1, done, seed))
+                fprintf(stderr, "render_image: checkpoint write failed: %s\n", drt_host_checkpoint_error());
             if (!(opt && opt->quiet)) printf("Checkpoint at %u / %u samples\n", done, p.spp);
         }
     }
@@ -169,7 +143,9 @@ int render_image_ex(config_arguments *config, const drt_host_options *opt, drt_s
                (f64)stats.shaded_vertices / (f64)stats.paths, (f64)stats.paths / (stats.total_ms * 1e3));
     }
 
-    int wrc = write_outputs(config, scene, width, height, dst_pixels, dst_avgs, dst_vars, (opt && opt->checkpoint_spp) ? raw_var_path : NULL);
+    int wrc = drt_host_write_outputs(config, width, height, S, scene->min_wavelength, scene->wavelength_interval, dst_pixels, dst_avgs, dst_vars,
+                                     (opt && opt->checkpoint_spp) ? 1 : 0, done, seed);
+    if (wrc) fprintf(stderr, "render_image: %s\n", drt_host_checkpoint_error());
     int w0 = wrc, w1 = 0, w2 = 0;
     /* post-process like the reference's main(): each .spd -> linear RGB -> BMP (src/win32_main.c:150-152) */
     if (!(w0 || w1 || w2) && config->output_bmp[0])

@@ -32,14 +32,21 @@ int drt_host_write_spd(const char *path, u32 width, u32 height, u32 num_wl, u32 
 
 int drt_host_read_spd(const char *path, spd_file_header *header, f64 **pixels)
 {
+    *pixels = NULL;
     FILE *f = fopen(path, "rb");
     if (!f) return -1;
     if (fread(header, sizeof(*header), 1, f) != 1 || header->id != 0xedfeefbe) { fclose(f); return -2; }
+    /* the header is not trusted: the pixel count it announces must be what the file holds */
     size_t per_pixel = (size_t)header->number_of_wavelengths + (header->has_filter_values ? 1 : 0);
-    size_t count = (size_t)header->width_in_pixels * header->height_in_pixels * per_pixel;
-    *pixels = (f64 *)malloc(count * sizeof(f64));
-    if (fread(*pixels, sizeof(f64), count, f) != count) { fclose(f); free(*pixels); *pixels = NULL; return -3; }
+    unsigned long long count = (unsigned long long)header->width_in_pixels * header->height_in_pixels * per_pixel;
+    long at = ftell(f);
+    fseek(f, 0, SEEK_END);
+    long end = ftell(f);
+    fseek(f, at, SEEK_SET);
+    if (at < 0 || end < at || count > (unsigned long long)(end - at) / sizeof(f64)) { fclose(f); return -3; }
+    *pixels = (f64 *)malloc((size_t)(count ? count : 1) * sizeof(f64));
+    if (!*pixels) { fclose(f); return -4; }
+    if (fread(*pixels, sizeof(f64), (size_t)count, f) != (size_t)count) { fclose(f); free(*pixels); *pixels = NULL; return -3; }
     fclose(f);
     return 0;
 }
-

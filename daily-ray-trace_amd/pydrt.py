@@ -322,6 +322,8 @@ def hip_lib():
                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(Stats)]
         L.drt_selftest_arith.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                          C.POINTER(C.c_double), C.c_uint64]
+        L.drt_selftest_unit.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_double), C.c_uint32,
+                                        C.c_uint64]
         _hip = L
     return _hip
 
@@ -329,6 +331,7 @@ def hip_lib():
 HIP_SYMBOLS = ["drt_last_error", "drt_device_count", "drt_create", "drt_destroy", "drt_bind_film", "drt_set_stream",
                "drt_render", "drt_synchronize", "drt_reset_film", "drt_film_device_ptrs", "drt_read_film", "drt_write_film",
                "drt_read_xyz", "drt_read_hit_indices", "drt_get_stats", "drt_batch_spp", "drt_render_tile", "drt_selftest_arith",
+               "drt_selftest_unit",
                "drt_group_create", "drt_group_destroy", "drt_group_size", "drt_group_render", "drt_group_synchronize",
                "drt_group_read_film", "drt_group_write_film", "drt_group_get_stats", "drt_render_tile_multi"]
 
@@ -492,6 +495,25 @@ def selftest_arith(op, a, b=None, device=0):
     out = np.empty(2 * n if op == 2 else n, dtype=np.float64)
     _check(hip_lib().drt_selftest_arith(device, op, _ptr(a, C.c_double), _ptr(b, C.c_double), _ptr(out, C.c_double), n),
            "drt_selftest_arith")
+    return out
+
+
+(UNIT_LINE_SPHERE, UNIT_LINE_PLANE, UNIT_REFLECT, UNIT_TRANSMIT, UNIT_ROTATION_BETWEEN, UNIT_SAMPLE_SPHERE, UNIT_SAMPLE_DISC,
+ UNIT_GGX, UNIT_GGX_ATT, UNIT_FS_DIELECTRIC, UNIT_FS_CONDUCTOR, UNIT_SEED_AND_DRAW) = range(12)
+_UNIT_OUT = {UNIT_LINE_SPHERE: 1, UNIT_LINE_PLANE: 1, UNIT_REFLECT: 3, UNIT_TRANSMIT: 3, UNIT_ROTATION_BETWEEN: 9,
+             UNIT_SAMPLE_SPHERE: 4, UNIT_SAMPLE_DISC: 4, UNIT_GGX: 1, UNIT_GGX_ATT: 1, UNIT_FS_DIELECTRIC: 1, UNIT_FS_CONDUCTOR: 1,
+             UNIT_SEED_AND_DRAW: 2}
+
+
+def selftest_unit(func, records, device=0):
+    """One of the path's device functions over `records` ([n][k] doubles; u64 arguments as their bit patterns). Returns [n][m]."""
+    rec = np.ascontiguousarray(records, dtype=np.float64)
+    if rec.ndim == 1:
+        rec = rec.reshape(-1, 1)
+    n, k = rec.shape
+    m = _UNIT_OUT[func]
+    out = np.zeros((n, m), dtype=np.float64)
+    _check(hip_lib().drt_selftest_unit(device, func, _ptr(rec, C.c_double), k, _ptr(out, C.c_double), m, n), "drt_selftest_unit")
     return out
 
 

@@ -6,8 +6,8 @@
  * The reference expands the list into prototypes, name tables and function-pointer tables
  * (src/bdsf.h:4-52). Here it is expanded into
  *   - integer IDs                       include/drt_hip.h   (DRT_BDSF_<name>, DRT_DIRF_<name>)
- *   - name tables for the .scn parser   daily-ray-trace_amd/host/bdsf_names.c
- *   - a device-side `switch`            daily-ray-trace_amd/csrc/drt_kernels.hip
+ *   - name tables for the .scn parser   daily-ray-trace_amd/host/drt_scene.c   (bdsf_name_list, dir_func_name_list)
+ *   - a device-side `switch`            daily-ray-trace_amd/csrc/drt_kernels.h  (bdsf_at_wavelength, sample_direction)
  * Adding a scattering function = one BDSF() line here + one device function + one oracle function.
  *
  * Define BDSF(name) and DIRF(name) before including; no include guard on purpose.

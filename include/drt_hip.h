@@ -267,6 +267,24 @@ int drt_render_tile_multi(const drt_scene *scene, const drt_camera *camera, cons
  * 1 a/b, 2 sincos(a) -> out[2*i], out[2*i+1], 3 pow(a,b), 4 rng stream from key a (as u64 bits). */
 int drt_selftest_arith(int device, int op, const double *a, const double *b, double *out, uint64_t n);
 
+/* Device-function self-test: runs ONE of the path's device functions -- the very __device__ function the trace / shade
+ * kernels call -- over n records (`in_stride` doubles in, `out_stride` doubles out per record), so that the edge cases of
+ * the reference's functions (tangent / parallel / on-boundary rays, antiparallel rotation, disc centre, total internal
+ * reflection) meet the HIP code directly and not only when a random scene happens to produce them. func:
+ *   0 line_sphere_intersection  src/geometry.c:123-146   in o[3] d[3] c[3] r                 out t
+ *   1 line_plane_intersection   src/geometry.c:157-182   in o[3] d[3] p[3] n[3] u[3] v[3]    out t
+ *   2 vec3_reflect              src/geometry.c:85-90     in v[3] n[3]                        out r[3]
+ *   3 vec3_transmit             src/geometry.c:92-106    in v[3] n[3] ir tr                  out t[3] (NaN on total internal reflection)
+ *   4 find_rotation_between_vectors src/geometry.c:263-295  in v[3] w[3]                     out m[9], columns
+ *   5 uniform_sample_sphere     src/rng.c:14-23          in rng state (u64 bits)             out p[3], state after (u64 bits)
+ *   6 uniform_sample_disc       src/rng.c:25-51          in rng state (u64 bits)             out p[3], state after (u64 bits)
+ *   7 ggx                       src/bdsf.c:3-20          in sn[3] mn[3] roughness            out D
+ *   8 ggx_att                   src/bdsf.c:22-42         in v[3] sn[3] mn[3] roughness       out D * G1
+ *   9 fs_dielectric_reflectance src/bdsf.c:44-67         in ir tr cos (one wavelength)       out R
+ *  10 fs_conductor_reflectance  src/bdsf.c:78-101        in ir tr te cos (one wavelength)    out R
+ *  11 seed_rng + rng            src/rng.c:1-12 (8a-R)    in path key (u64 bits)              out state (u64 bits), first rng() */
+int drt_selftest_unit(int device, int func, const double *in, uint32_t in_stride, double *out, uint32_t out_stride, uint64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,6 +143,10 @@ class RefSurfaceInput(C.Structure):
                 ("u", C.c_double * 3), ("v", C.c_double * 3)]
 
 
+# int drt_render_tile(scene, camera, params, pixels, avgs, vars, stats): the boundary's one-shot entry point (include/drt_hip.h)
+RENDER_TILE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(pydrt.Scene), C.POINTER(pydrt.Camera), C.POINTER(pydrt.Params), f64p, f64p, f64p,
+                             C.POINTER(pydrt.Stats))
+
 SPD_METHOD_NONE, SPD_METHOD_RGB, SPD_METHOD_CSV, SPD_METHOD_BLACKBODY, SPD_METHOD_CONST = range(5)  # src/read_scene.h:15-23
 
 _ref = None
@@ -214,6 +218,7 @@ def ref_lib():
         L.ref_spectrum_normalise.argtypes = [f64p]
         L.ref_spectral_mul_by_scalar.argtypes = [f64p, C.c_double]
         L.ref_const_spectrum.argtypes = [f64p, C.c_double]
+        L.ref_run_binding.argtypes = [Cm, P, RENDER_TILE_FN, f64p, f64p, f64p]
         _ref = L
     return _ref
 

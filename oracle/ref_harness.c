@@ -101,7 +101,7 @@ REF_API double ref_rng(void) { return rng(); }
 /* ---- spectral grid and tables (the reference's globals, filled from the boundary structs) ---- */
 static f64 *g_block = NULL;
 
-REF_API void ref_set_grid(uint32_t n, double min_wl, double interval)
+static void set_grid_rows(uint32_t n, double min_wl, double interval, uint32_t scene_rows)
 {
     number_of_spectrum_samples = n;
     smallest_wavelength = min_wl;
@@ -109,8 +109,15 @@ REF_API void ref_set_grid(uint32_t n, double min_wl, double interval)
     largest_wavelength = min_wl + (n - 1) * interval;
     spectrum_size = n * sizeof(f64);
     free(g_block);
-    uint32_t stack_capacity = 32; /* src/daily_ray_trace.c:658 */
+    /* one block like init_spd_tables' (src/spectrum.c:10-34): 4 cmfs, 7 rgb tables, then the stack; `scene_rows` spectra
+     * of a scene are taken from the bottom of the stack, as init_spd's alloc_spd() calls would */
+    uint32_t stack_capacity = 32 + scene_rows; /* src/daily_ray_trace.c:658 says 32; scenes built here may hold more spectra */
     g_block = (f64 *)calloc((size_t)(11 + stack_capacity) * n, sizeof(f64));
+    spd_alloc_table.size = (11 + stack_capacity) * spectrum_size;
+    spd_alloc_table.base = g_block;
+    spd_alloc_table.cmf_base = g_block;
+    spd_alloc_table.rgb_base = g_block + 4 * n;
+    spd_alloc_table.stack_base = g_block + 11 * n;
     cmfs.rw.samples = g_block + 0 * n;
     cmfs.x.samples = g_block + 1 * n;
     cmfs.y.samples = g_block + 2 * n;
@@ -123,10 +130,11 @@ REF_API void ref_set_grid(uint32_t n, double min_wl, double interval)
     rgb_spds.magenta.samples = g_block + 9 * n;
     rgb_spds.yellow.samples = g_block + 10 * n;
     spd_stack.capacity = stack_capacity;
-    spd_stack.allocated = 0;
+    spd_stack.allocated = scene_rows;
     spd_stack.base = g_block + 11 * n;
-    spd_stack.next = spd_stack.base;
+    spd_stack.next = spd_stack.base + (size_t)scene_rows * n;
 }
+REF_API void ref_set_grid(uint32_t n, double min_wl, double interval) { set_grid_rows(n, min_wl, interval, 0); }
 /* tables: [11][n] = rw, x, y, z, white, red, green, blue, cyan, magenta, yellow */
 REF_API void ref_set_tables(const double *tables) { memcpy(g_block, tables, (size_t)11 * number_of_spectrum_samples * sizeof(f64)); }
 
@@ -222,8 +230,8 @@ REF_API void ref_fs_conductor_reflectance(const double *ir, const double *tr, co
 
 /* ---- scene in the reference's own structs ---------------------------------------------------- */
 static scene_data g_scene;
-static f64 *g_scene_spds = NULL;
-static f64 *g_zero = NULL;
+static f64 *g_scene_spds = NULL; /* the scene's spectra: rows 11.. of the one block, where init_spd would have put them */
+static f64 *g_zero = NULL;       /* one all-zero row after them: stands for a spectrum the scene does not give (the boundary's -1) */
 
 static spectrum spd_at(const drt_scene *sc, int32_t idx)
 {
@@ -237,17 +245,17 @@ static spectrum spd_at(const drt_scene *sc, int32_t idx)
 REF_API void ref_set_scene(const drt_scene *sc)
 {
     uint32_t S = sc->num_wavelengths;
-    ref_set_grid(S, sc->min_wavelength, sc->wavelength_interval);
+    set_grid_rows(S, sc->min_wavelength, sc->wavelength_interval, sc->num_spds + 1);
     if (sc->num_spds >= 11) ref_set_tables(sc->spds);
     /* colour-matching tables may sit elsewhere in the block */
     memcpy(cmfs.rw.samples, sc->spds + (size_t)sc->cmf_rw * S, S * sizeof(f64));
     memcpy(cmfs.x.samples, sc->spds + (size_t)sc->cmf_x * S, S * sizeof(f64));
     memcpy(cmfs.y.samples, sc->spds + (size_t)sc->cmf_y * S, S * sizeof(f64));
     memcpy(cmfs.z.samples, sc->spds + (size_t)sc->cmf_z * S, S * sizeof(f64));
-    free(g_scene_spds); free(g_zero); free(g_scene.surfaces); free(g_scene.scene_materials);
-    g_scene_spds = (f64 *)malloc((size_t)sc->num_spds * S * sizeof(f64));
+    free(g_scene.surfaces); free(g_scene.scene_materials);
+    g_scene_spds = spd_stack.base;
     memcpy(g_scene_spds, sc->spds, (size_t)sc->num_spds * S * sizeof(f64));
-    g_zero = (f64 *)calloc(S, sizeof(f64));
+    g_zero = g_scene_spds + (size_t)sc->num_spds * S; /* zero-filled by calloc */
     memset(&g_scene, 0, sizeof(g_scene));
     g_scene.num_surfaces = sc->num_surfaces;
     g_scene.num_scene_materials = sc->num_materials;
@@ -626,5 +634,43 @@ REF_API int ref_csv_to_spectrum(const char *path, double *dst)
 REF_API void ref_spectrum_normalise(double *spd) { spectrum s; s.samples = spd; spectrum_normalise(s); }
 REF_API void ref_spectral_mul_by_scalar(double *spd, double f) { spectrum s; s.samples = spd; spectral_mul_by_scalar(s, s, f); }
 REF_API void ref_const_spectrum(double *spd, double f) { spectrum s; s.samples = spd; const_spectrum(s, f); }
+
+/* ---- the reference-side binding of INTEGRATION.md, compiled as the maintainer would add it ------------------ */
+/* include/drt_reference_binding.inc is the text INTEGRATION.md shows. Its one call into the library goes through a
+ * pointer here, so that a test can hand it any implementation of the boundary (libdrt_hip.so's, or the oracle behind the
+ * same signature) without this library linking against either. */
+typedef int (*render_tile_fn)(const drt_scene *, const drt_camera *, const drt_params *, double *, double *, double *, drt_stats *);
+static render_tile_fn g_render_tile = NULL;
+static const char *binding_last_error(void) { return "the boundary implementation handed to ref_run_binding failed"; }
+#define drt_render_tile g_render_tile
+#define drt_last_error binding_last_error
+#define printf ref_quiet_printf
+#define exit ref_parse_exit
+#include "../include/drt_reference_binding.inc"
+#undef exit
+#undef printf
+#undef drt_last_error
+#undef drt_render_tile
+
+/* Runs render_pixels_mi355x() on the scene ref_set_scene() built, with config_arguments / camera_data made from the
+ * boundary structs, and `fn` as drt_render_tile. Returns 0, or nonzero when the stub took its exit(-1) path. */
+REF_API int ref_run_binding(const drt_camera *c, const drt_params *p, render_tile_fn fn, double *pixels, double *avgs, double *vars)
+{
+    camera_data camera = cam_in(c);
+    config_arguments config;
+    memset(&config, 0, sizeof(config));
+    config.output_width = p->width;
+    config.output_height = p->height;
+    config.num_pixel_samples = p->spp;
+    config.max_cast_depth = p->max_depth;
+    config.pixel_scheme = (film_sample_scheme)p->pixel_scheme;
+    g_render_tile = fn;
+    int rc = 0;
+    g_parse_active = 1;
+    if ((rc = setjmp(g_parse_jmp)) == 0) render_pixels_mi355x(&config, &g_scene, &camera, pixels, avgs, vars);
+    g_parse_active = 0;
+    g_render_tile = NULL;
+    return rc;
+}
 
 REF_API int ref_version(void) { return 2; }

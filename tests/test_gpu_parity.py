@@ -65,6 +65,94 @@ def test_device_arithmetic_is_ieee_and_matches_the_oracle_spec():
         assert got[i] == v
 
 
+def _xorshift(x):
+    x ^= (x << 13) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 7
+    x ^= (x << 17) & 0xFFFFFFFFFFFFFFFF
+    return x
+
+
+def test_device_functions_on_the_reference_edge_cases(golden_dir):
+    """The path's __device__ functions, called one by one through drt_selftest_unit, on the reference's own outputs
+    (tests/golden/unit_*.npz: tangent, behind, parallel and on-boundary rays, total internal reflection, antiparallel
+    rotation ...): bit-exact wherever the function is + - x / sqrt only, bit-exact against the oracle's DEVICE arithmetic
+    and within 1e-13 of the reference where PI or sin/cos come in (x87 long double there)."""
+    def g_load(name):
+        return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+    L = O.oracle_lib()
+    g = g_load("unit_geometry.npz")
+    # intersectors (src/geometry.c:123-182)
+    sph = pydrt.selftest_unit(pydrt.UNIT_LINE_SPHERE, np.hstack([g["sph_o"], g["sph_d"], g["sph_c"], g["sph_r"][:, None]]))[:, 0]
+    assert np.array_equal(sph, g["sph_t"]) and np.isinf(sph).any() and (sph == 0.0).any()
+    pl = pydrt.selftest_unit(pydrt.UNIT_LINE_PLANE, np.hstack([g["pl_o"], g["pl_d"], g["pl_p"], g["pl_n"], g["pl_u"], g["pl_v"]]))[:, 0]
+    assert np.array_equal(pl, g["pl_t"]) and np.isinf(pl[910:930]).all() and np.all(pl[900:907] == 1.0)
+    # hand-made edge cases against the oracle: tangent ray, origin inside / on the sphere, sphere behind; plane hit exactly on
+    # its edges and corners (inclusive bounds), parallel ray, plane behind
+    e_s = np.array([[0, 1, 5, 0, 0, -1, 0, 0, 0, 1], [0, 0, 0, 0, 0, -1, 0, 0, 0, 1], [0, 0, 1, 0, 0, -1, 0, 0, 0, 1],
+                    [0, 0, -3, 0, 0, -1, 0, 0, 0, 1], [0, 1 + 1e-16, 5, 0, 0, -1, 0, 0, 0, 1], [0.6, 0.8, 5, 0, 0, -1, 0, 0, 0, 1]], dtype=np.float64)
+    want = [L.drt_oracle_line_sphere(O._v3(r[0:3]), O._v3(r[3:6]), O._v3(r[6:9]), float(r[9])) for r in e_s]
+    assert np.array_equal(pydrt.selftest_unit(pydrt.UNIT_LINE_SPHERE, e_s)[:, 0], np.array(want))
+    pp, pn, pu, pv = [-0.5, -0.5, 0], [0, 0, 1], [1, 0, 0], [0, 1, 0]
+    e_p = np.array([[x, y, 1, 0, 0, dz] + pp + pn + pu + pv for (x, y, dz) in
+                    ((-0.5, -0.5, -1), (0.5, 0.5, -1), (0.5, -0.5, -1), (0.5 + 1e-16, 0, -1), (0.5000001, 0, -1), (0, 0, 1), (0, -0.5, -1))]
+                   + [[0, 0, 1, 1, 0, 0] + pp + pn + pu + pv], dtype=np.float64)
+    want = [L.drt_oracle_line_plane(O._v3(r[0:3]), O._v3(r[3:6]), O._v3(r[6:9]), O._v3(r[9:12]), O._v3(r[12:15]), O._v3(r[15:18])) for r in e_p]
+    got = pydrt.selftest_unit(pydrt.UNIT_LINE_PLANE, e_p)[:, 0]
+    assert np.array_equal(got, np.array(want)) and got[0] == 1.0 and got[1] == 1.0 and np.isinf(got[4]) and np.isinf(got[5]) and np.isinf(got[7])
+    # reflect / transmit (NaN on total internal reflection) / Rodrigues rotation (antiparallel -> -I)
+    assert np.array_equal(pydrt.selftest_unit(pydrt.UNIT_REFLECT, np.hstack([g["rf_v"], g["rf_n"]])), g["rf_reflect"])
+    tr = pydrt.selftest_unit(pydrt.UNIT_TRANSMIT, np.hstack([g["rf_v"], g["rf_n"], g["rf_ir"][:, None], g["rf_tr"][:, None]]))
+    assert np.array_equal(tr, g["rf_transmit"], equal_nan=True) and np.isnan(tr).any()
+    z = np.tile([0.0, 0.0, 1.0], (len(g["rot_w"]), 1))
+    rot = pydrt.selftest_unit(pydrt.UNIT_ROTATION_BETWEEN, np.hstack([z, g["rot_w"]]))
+    assert np.array_equal(rot, g["rot_m"]) and np.array_equal(rot[0], -np.eye(3).ravel())
+    same = pydrt.selftest_unit(pydrt.UNIT_ROTATION_BETWEEN, np.array([[0, 0, 1, 0, 0, 1], [0, 0, 1, 0, 0, -1]], dtype=np.float64))
+    assert np.array_equal(same[0], np.eye(3).ravel()) and np.array_equal(same[1], -np.eye(3).ravel())
+
+    # seeding, first draw, shape samplers (src/rng.c) -- the fixture's flow: seed, rng(), sphere (2 draws), disc (2 draws)
+    q = g_load("unit_sampling.npz")
+    sd = pydrt.selftest_unit(pydrt.UNIT_SEED_AND_DRAW, q["keys"].view(np.float64))
+    assert np.array_equal(sd[:, 0].copy().view(np.uint64), q["state"]) and np.array_equal(sd[:, 1], q["first"])
+    s1 = np.array([_xorshift(int(x)) for x in q["state"]], dtype=np.uint64)
+    sph = pydrt.selftest_unit(pydrt.UNIT_SAMPLE_SPHERE, s1.view(np.float64))
+    s3 = sph[:, 3].copy().view(np.uint64)
+    disc = pydrt.selftest_unit(pydrt.UNIT_SAMPLE_DISC, s3.view(np.float64))
+    assert np.array_equal(disc[:, 3].copy().view(np.uint64), q["state_after"])
+    np.testing.assert_allclose(sph[:, :3], q["sphere"], rtol=1e-13, atol=1e-16)
+    np.testing.assert_allclose(disc[:, :3], q["disc"], rtol=1e-13, atol=1e-16)
+    O.set_math_mode(O.MATH_DEVICE)
+    out = np.zeros(3)
+    for i in range(0, len(s1), 5):
+        L.drt_oracle_set_rng_state(int(s1[i]))
+        L.drt_oracle_uniform_sample_sphere(O._ptr(out))
+        assert np.array_equal(out, sph[i, :3])
+        L.drt_oracle_uniform_sample_disc(O._ptr(out))
+        assert np.array_equal(out, disc[i, :3])
+    # GGX (src/bdsf.c:3-42) and the Fresnel loop bodies (:44-101)
+    sp = g_load("unit_spectral.npz")
+    d = pydrt.selftest_unit(pydrt.UNIT_GGX, np.hstack([sp["ggx_sn"], sp["ggx_mn"], sp["ggx_rough"][:, None]]))[:, 0]
+    da = pydrt.selftest_unit(pydrt.UNIT_GGX_ATT, np.hstack([sp["ggx_v"], sp["ggx_sn"], sp["ggx_mn"], sp["ggx_rough"][:, None]]))[:, 0]
+    np.testing.assert_allclose(d, sp["ggx"], rtol=1e-13, atol=1e-300)
+    np.testing.assert_allclose(da, sp["ggx_att"], rtol=1e-13, atol=1e-300)
+    for i in range(len(d)):
+        a = L.drt_oracle_ggx(O._v3(sp["ggx_sn"][i]), O._v3(sp["ggx_mn"][i]), float(sp["ggx_rough"][i]))
+        b = L.drt_oracle_ggx_att(O._v3(sp["ggx_v"][i]), O._v3(sp["ggx_sn"][i]), O._v3(sp["ggx_mn"][i]), float(sp["ggx_rough"][i]))
+        assert a == d[i] and b == da[i]
+    O.set_math_mode(O.MATH_REFERENCE)
+    S = len(sp["glass"])
+    cos = np.repeat(sp["cosines"], S)
+    vac, glass, au_n, au_k = (np.tile(sp[k], len(sp["cosines"])) for k in ("vac", "glass", "au_n", "au_k"))
+    r_out = pydrt.selftest_unit(pydrt.UNIT_FS_DIELECTRIC, np.stack([vac, glass, cos], axis=1))[:, 0].reshape(-1, S)
+    r_in = pydrt.selftest_unit(pydrt.UNIT_FS_DIELECTRIC, np.stack([glass, vac, cos], axis=1))[:, 0].reshape(-1, S)
+    r_c = pydrt.selftest_unit(pydrt.UNIT_FS_CONDUCTOR, np.stack([vac, au_n, au_k, cos], axis=1))[:, 0].reshape(-1, S)
+    assert np.array_equal(r_out, sp["diel_r"]) and np.array_equal(r_in, sp["diel_r_inside"]) and np.array_equal(r_c, sp["cond_r"])
+    assert (r_in == 1.0).any()  # the total-internal-reflection branch
+    # argument checks: records narrower than the function reads are refused, not read past
+    with pytest.raises(RuntimeError):
+        pydrt.selftest_unit(pydrt.UNIT_LINE_PLANE, np.zeros((4, 10)))
+
+
 @pytest.mark.parametrize("name", list(cases.RENDER_CASES))
 def test_hip_matches_oracle_and_golden(name, golden_dir):
     bundle, params = cases.load_case(name)
@@ -420,7 +508,9 @@ def test_full_size_properties_config2():
 
 
 FULL_SIZE_CONFIGS = {
-    # BASELINE.json configs 3, 4, 5 exactly as named there (config 2 is the bench workload and has its own test above)
+    # BASELINE.json configs 2, 3, 4, 5 exactly as named there (config 2 is also the bench workload; its size-independent
+    # properties at 8 spp are the test above, here it runs at its stated 256 spp)
+    "config2_plane_light_1024_256spp_d8": (lambda: pydrt.load_scene(cases.scene_path("cornell_plane_light.scn"), 1024, 1024), 1024, 256, 8),
     "config3_large_box_2048_1024spp_d16": (lambda: pydrt.load_scene(cases.scene_path("cornell_large_box.scn"), 2048, 2048), 2048, 1024, 16),
     "config4_gold_mirror_1024_512spp_d8": (lambda: pydrt.load_scene(cases.scene_path("cornell_gold_mirror.scn"), 1024, 1024), 1024, 512, 8),
     "config5_10k_spheres_4096_64spp_d8": (lambda: pydrt.synthetic_sphere_scene(10000, 4096, 4096), 4096, 64, 8),

@@ -204,3 +204,98 @@ def test_spd_to_bmp_postprocess(tmp_path, golden_dir):
     expect = (np.clip(g["rgb_back"][:6], 0.0, 1.0) * 255.0).astype(np.uint8)  # clamp, truncate, no gamma
     assert np.array_equal(px[:, 2], expect[:, 0]) and np.array_equal(px[:, 1], expect[:, 1]) and np.array_equal(px[:, 0], expect[:, 2])
     assert np.all(px[:, 3] == 255)
+
+
+def _config_for(workdir):
+    """A config_arguments (1136 bytes, the reference's layout) whose outputs live under workdir."""
+    H = pydrt.host_lib()
+    text = ("num_pixel_samples 6\nmax_cast_depth 4\noutput_width 5\noutput_height 3\nmin_wl 380.0\nmax_wl 720.0\nwl_interval 5.0\n"
+            "pixel_scheme pixel_random\ninput_scene scenes/cornell_plane_light.scn\n"
+            "output_spd %s/output.spd\naverage_spd %s/average.spd\nvariance_spd %s/variance.spd\n" % (workdir, workdir, workdir)).encode()
+    buf = C.create_string_buffer(1136)
+    tb = C.create_string_buffer(text, len(text) + 1)
+    H.parse_config.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p]
+    H.parse_config.restype = None
+    H.parse_config(tb, len(text), buf)
+    return buf
+
+
+def test_checkpoint_sets_are_crash_safe_and_resume_refuses_mixed_files(tmp_path):
+    """a checkpoint is four files; a kill between them must never let a later resume continue from a mixed
+    set. Files go through .tmp + rename with a manifest written last, and the loader refuses anything inconsistent."""
+    import shutil
+    H = pydrt.host_lib()
+    f64p = C.POINTER(C.c_double)
+    H.drt_host_write_outputs.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, f64p, f64p, f64p,
+                                         C.c_int, C.c_uint32, C.c_uint64]
+    H.drt_host_load_checkpoint.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, f64p, f64p, f64p,
+                                           C.POINTER(C.c_uint32)]
+    H.drt_host_checkpoint_error.restype = C.c_char_p
+    w, h, S = 5, 3, 69
+    n_px = w * h
+    rng = np.random.default_rng(3)
+    import tempfile
+    short = tempfile.mkdtemp(prefix="ck", dir="/tmp")  # config_arguments path fields hold 63 characters (src/daily_ray_trace.h:36-52)
+
+    def film(n):
+        """a film that is consistent with n samples: sums, filter = n, mean = sum / n, variance >= 0"""
+        px = np.zeros((n_px, S + 1)); px[:, :S] = rng.uniform(0, 5, (n_px, S)) * n; px[:, S] = n
+        return px, px[:, :S] / n, rng.uniform(0, 2, (n_px, S))
+
+    def write(d, n, seed=1, raw=1):
+        os.makedirs(d, exist_ok=True)
+        cfg = _config_for(d)
+        px, av, va = film(n)
+        assert H.drt_host_write_outputs(cfg, w, h, S, 380.0, 5.0, px.ctypes.data_as(f64p), av.ctypes.data_as(f64p), va.ctypes.data_as(f64p), raw, n, seed) == 0
+        return cfg, px, av, va
+
+    def load(cfg, seed=1, size=(w, h)):
+        a, b, c = np.zeros((size[0] * size[1], S + 1)), np.zeros((size[0] * size[1], S)), np.zeros((size[0] * size[1], S))
+        done = C.c_uint32(77)
+        rc = H.drt_host_load_checkpoint(cfg, size[0], size[1], S, seed, a.ctypes.data_as(f64p), b.ctypes.data_as(f64p), c.ctypes.data_as(f64p), C.byref(done))
+        return rc, done.value, a, b, c, H.drt_host_checkpoint_error().decode()
+
+    d2 = os.path.join(short, "n4")
+    cfg, px, av, va = write(d2, 4)
+    assert not [f for f in os.listdir(d2) if f.endswith(".tmp")]          # nothing half-written is left behind
+    assert sorted(os.listdir(d2)) == ["average.spd", "output.spd", "output.spd.ckpt", "variance.spd", "variance.spd.raw"]
+    rc, done, a, b, c, why = load(cfg)
+    assert rc == 0 and done == 4 and np.array_equal(a, px) and np.array_equal(b, av) and np.array_equal(c, va)
+    # the advisor's case: output.spd already at N2 = 4 samples, average.spd still from N1 = 2
+    d1 = os.path.join(short, "n2")
+    write(d1, 2)
+    shutil.copy(os.path.join(d1, "average.spd"), os.path.join(d2, "average.spd"))
+    rc, done, *_, why = load(cfg)
+    assert rc != 0 and done == 0 and "does not belong" in why
+    # the whole older set under a newer manifest: the filter sums give it away
+    cfg, *_ = write(d2, 4)
+    shutil.copy(os.path.join(d1, "output.spd"), os.path.join(d2, "output.spd"))
+    rc, done, *_, why = load(cfg)
+    assert rc != 0 and "manifest says 4" in why
+    # a kill between the renames and the manifest: no manifest, no resume
+    cfg, *_ = write(d2, 4)
+    os.remove(os.path.join(d2, "output.spd.ckpt"))
+    rc, done, *_, why = load(cfg)
+    assert rc != 0 and "manifest" in why
+    # a final write without the raw variance retires the manifest of the set it overwrote
+    cfg, *_ = write(d2, 4)
+    write(d2, 6, raw=0)
+    assert not os.path.exists(os.path.join(d2, "output.spd.ckpt")) and load(cfg)[0] != 0
+    # other job: another seed, another size; a truncated file; a file of another size with a forged header
+    cfg, *_ = write(d2, 4)
+    assert load(cfg, seed=2)[0] != 0 and "seed" in load(cfg, seed=2)[5]
+    assert load(cfg, size=(3, 5))[0] != 0
+    raw_path = os.path.join(d2, "variance.spd.raw")
+    data = open(raw_path, "rb").read()
+    open(raw_path, "wb").write(data[:-8])
+    rc, _, _, _, _, why = load(cfg)
+    assert rc != 0 and "bytes" in why
+    open(raw_path, "wb").write(data)
+    assert load(cfg)[0] == 0
+    hdr = np.frombuffer(data[:40], dtype=np.uint32).copy(); hdr[1] = 1 << 30; hdr[2] = 1 << 30   # a header that announces 2^60 pixels
+    open(raw_path, "wb").write(hdr.tobytes() + data[40:])
+    H.drt_host_read_spd.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(f64p)]
+    out = f64p()
+    assert H.drt_host_read_spd(raw_path.encode(), C.create_string_buffer(40), C.byref(out)) != 0 and not out
+    assert load(cfg)[0] != 0
+    shutil.rmtree(short)

@@ -128,3 +128,56 @@ def test_host_scene_build_pieces_on_random_inputs():
         R.ref_init_camera(C.byref(cam_r), p(pos.copy()), p(tgt.copy()), roll, fov, fdepth, flength, aperture, w, h)
         np.testing.assert_allclose(np.frombuffer(bytes(cam_h), dtype=np.float64), np.frombuffer(bytes(cam_r), dtype=np.float64),
                                    rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("name", ["plane_light_16", "gold_mirror", "lights", "init_cornell"])
+def test_integration_stub_round_trips_a_scene(name):
+    """INTEGRATION.md's reference-side binding (include/drt_reference_binding.inc, compiled here against the reference's own
+    headers as a maintainer would add it to src/daily_ray_trace.c): the reference's scene_data / camera_data / config go in,
+    the boundary structs of include/drt_hip.h come out and reach drt_render_tile -- here the oracle behind that signature.
+    The film must be, bit for bit, the film of the scene the boundary structs came from, i.e. flattening loses nothing."""
+    import ctypes as C
+    bundle, params = cases.load_case(name)
+    R = O.ref_lib()
+    R.ref_set_scene(C.byref(bundle.scene))
+    S = bundle.S
+    n = int(params.width) * int(params.height)
+    seen = {}
+
+    def render_tile(sc, cam, p, px, av, va, st):
+        sc, cam, p = sc.contents, cam.contents, p.contents
+        seen.update(num_spds=int(sc.num_spds), num_materials=int(sc.num_materials), num_surfaces=int(sc.num_surfaces),
+                    cmf=(int(sc.cmf_rw), int(sc.cmf_x), int(sc.cmf_y), int(sc.cmf_z)), flags=int(p.flags), spp=int(p.spp),
+                    base=int(sc.base_material), escape=int(sc.escape_material))
+        b2 = pydrt.SceneBundle(sc, cam)
+        opx, oav, ova, _, ost = O.oracle_render_tile(b2, p, math_mode=O.MATH_REFERENCE)
+        for dst, src in ((px, opx), (av, oav), (va, ova)):
+            C.memmove(dst, src.ctypes.data, src.nbytes)
+        st.contents.paths = ost.paths
+        return 0
+
+    px, av, va = np.zeros((n, S + 1)), np.zeros((n, S)), np.zeros((n, S))
+    p1 = pydrt.make_params(int(params.width), int(params.height), spp=int(params.spp), max_depth=int(params.max_depth), seed=1,
+                           pixel_scheme=int(params.pixel_scheme))
+    rc = R.ref_run_binding(C.byref(bundle.camera), C.byref(p1), O.RENDER_TILE_FN(render_tile), O._ptr(px), O._ptr(av), O._ptr(va))
+    assert rc == 0
+    sc = bundle.scene
+    assert seen["num_materials"] == sc.num_materials and seen["num_surfaces"] == sc.num_surfaces
+    assert seen["num_spds"] == 11 + sc.num_spds + 1 and seen["cmf"] == (0, 1, 2, 3)  # tables, the scene's rows, the zero row
+    assert seen["base"] == sc.base_material and seen["escape"] == sc.escape_material
+    assert seen["flags"] == pydrt.FLAG_FILM_ZERO and seen["spp"] == int(params.spp)
+    opx, oav, ova, _, _ = O.oracle_render_tile(bundle, p1, math_mode=O.MATH_REFERENCE)
+    assert np.array_equal(px, opx) and np.array_equal(av, oav) and np.array_equal(va, ova)
+    # and the reference's own pixel loop on the same scene agrees (the stub replaces exactly that loop)
+    rp, ra, rv = O.ref_render_tile(bundle, p1)
+    assert np.array_equal(px, rp) and np.array_equal(av, ra) and np.array_equal(va, rv)
+    # a failing launcher takes the stub's exit(-1) path
+    assert R.ref_run_binding(C.byref(bundle.camera), C.byref(p1), O.RENDER_TILE_FN(lambda *a: -7), O._ptr(px), O._ptr(av), O._ptr(va)) != 0
+
+
+def test_integration_md_shows_the_compiled_stub():
+    """The code block in INTEGRATION.md is the file that is compiled above, character for character."""
+    import os
+    stub = open(os.path.join(cases.REPO, "include", "drt_reference_binding.inc")).read().strip()
+    doc = open(os.path.join(cases.REPO, "INTEGRATION.md")).read()
+    assert stub in doc
