@@ -119,8 +119,8 @@ def test_device_functions_on_the_reference_edge_cases(golden_dir):
     s3 = sph[:, 3].copy().view(np.uint64)
     disc = pydrt.selftest_unit(pydrt.UNIT_SAMPLE_DISC, s3.view(np.float64))
     assert np.array_equal(disc[:, 3].copy().view(np.uint64), q["state_after"])
-    np.testing.assert_allclose(sph[:, :3], q["sphere"], rtol=1e-13, atol=1e-16)
-    np.testing.assert_allclose(disc[:, :3], q["disc"], rtol=1e-13, atol=1e-16)
+    np.testing.assert_allclose(sph[:, :3], q["sphere"], rtol=1e-13, atol=2e-15)  # unit vectors: absolute error of the f64 vs x87 sincos argument
+    np.testing.assert_allclose(disc[:, :3], q["disc"], rtol=1e-13, atol=2e-15)
     O.set_math_mode(O.MATH_DEVICE)
     out = np.zeros(3)
     for i in range(0, len(s1), 5):
