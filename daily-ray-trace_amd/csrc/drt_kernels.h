@@ -196,16 +196,42 @@ __device__ __forceinline__ double leaf_distance(const SceneView &sv, const BvhLe
     return surface_distance(sv, lp.index, lp.type, o, d);
 }
 
-/* ray vs padded box: entry distance, or a negative number when the box is missed / behind the ray */
-__device__ __forceinline__ double bvh_box_entry(const BvhNode &n, int c, V3 o, V3 inv_d)
+/* A ray as the box tests see it: origin and reciprocal direction in f32. The boxes only PRUNE, so their test may be as coarse
+ * as it likes as long as it never rejects a box the exact test would accept. Error budget of t = lo * inv - o * inv in f32
+ * (u = 2^-24): the conversions of o and 1/d, the product o * inv and the fused multiply-add together move a slab plane by at
+ * most 2u |o| + 2u |lo - o| in position, i.e. < 4.6e-5 for coordinates within 64; the builder pads every stored box by
+ * 2^-19 x (largest coordinate of the scene and the camera) on top of its f64 padding, more than twice that (see
+ * BvhBuilder::build). A NaN (0 x inf on an axis the ray is parallel to) drops out of min / max: that slab then does not
+ * constrain the interval, which errs on the accepting side. */
+struct Ray32
 {
-    double t0x = ((double)n.lo[c][0] - o.x) * inv_d.x, t1x = ((double)n.hi[c][0] - o.x) * inv_d.x;
-    double t0y = ((double)n.lo[c][1] - o.y) * inv_d.y, t1y = ((double)n.hi[c][1] - o.y) * inv_d.y;
-    double t0z = ((double)n.lo[c][2] - o.z) * inv_d.z, t1z = ((double)n.hi[c][2] - o.z) * inv_d.z;
-    double tmin = __builtin_fmax(__builtin_fmax(__builtin_fmin(t0x, t1x), __builtin_fmin(t0y, t1y)), __builtin_fmin(t0z, t1z));
-    double tmax = __builtin_fmin(__builtin_fmin(__builtin_fmax(t0x, t1x), __builtin_fmax(t0y, t1y)), __builtin_fmax(t0z, t1z));
-    if (!(tmax >= 0.0) || !(tmin <= tmax)) return -1.0;
-    return tmin > 0.0 ? tmin : 0.0;
+    float ix, iy, iz, nx, ny, nz; /* 1/d and -o/d */
+};
+__device__ __forceinline__ Ray32 bvh_ray32(V3 o, V3 d)
+{
+    Ray32 r;
+    r.ix = __builtin_amdgcn_rcpf((float)d.x); /* v_rcp_f32: 1 ulp, inside the budget above */
+    r.iy = __builtin_amdgcn_rcpf((float)d.y);
+    r.iz = __builtin_amdgcn_rcpf((float)d.z);
+    r.nx = -((float)o.x * r.ix);
+    r.ny = -((float)o.y * r.iy);
+    r.nz = -((float)o.z * r.iz);
+    return r;
+}
+/* a distance limit for f32 comparisons, rounded UP (inf stays inf, 0 stays 0) */
+__device__ __forceinline__ float bvh_limit32(double limit) { return (float)limit * 1.00000024f; }
+
+/* ray vs padded box: a LOWER bound of the entry distance (clamped at 0), or a negative number when the box is certainly
+ * missed or behind the ray */
+__device__ __forceinline__ float bvh_box_entry(const BvhNode &n, int c, const Ray32 &r)
+{
+    float t0x = __builtin_fmaf(n.lo[c][0], r.ix, r.nx), t1x = __builtin_fmaf(n.hi[c][0], r.ix, r.nx);
+    float t0y = __builtin_fmaf(n.lo[c][1], r.iy, r.ny), t1y = __builtin_fmaf(n.hi[c][1], r.iy, r.ny);
+    float t0z = __builtin_fmaf(n.lo[c][2], r.iz, r.nz), t1z = __builtin_fmaf(n.hi[c][2], r.iz, r.nz);
+    float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
+    float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
+    if (!(tmax >= 0.0f) || !(tmin <= tmax)) return -1.0f;
+    return tmin > 0.0f ? tmin : 0.0f;
 }
 
 /* Traversal state: a reference is an inner node index (>= 0), a leaf (< BVH_DONE: first slot and count packed), or
@@ -216,15 +242,16 @@ __device__ __forceinline__ double bvh_box_entry(const BvhNode &n, int c, V3 o, V
 __device__ __forceinline__ int bvh_leaf_ref(int first, int count) { return -2 - (first * 8 + (count - 1)); } /* count 1..8 */
 __device__ __forceinline__ bool bvh_is_leaf(int ref) { return ref < BVH_DONE; }
 
-/* the two children of inner node `node` against the ray: which are entered within `limit`, and where */
-__device__ __forceinline__ void bvh_children(const BvhNode &n, V3 o, V3 inv_d, double limit, bool strict, int ref[2], double t[2], bool hit[2])
+/* the two children of inner node `node` against the ray: which may be entered within `limit` (an f32 upper bound of the
+ * distance limit), and a lower bound of where */
+__device__ __forceinline__ void bvh_children(const BvhNode &n, const Ray32 &r, float limit, int ref[2], float t[2], bool hit[2])
 {
 #pragma unroll
     for (int c = 0; c < 2; c += 1)
     {
         const int cnt = n.count[c];
-        t[c] = bvh_box_entry(n, c, o, inv_d);
-        hit[c] = cnt >= 0 && t[c] >= 0.0 && (strict ? t[c] < limit : t[c] <= limit);
+        t[c] = bvh_box_entry(n, c, r);
+        hit[c] = cnt >= 0 && t[c] >= 0.0f && t[c] <= limit;
         ref[c] = cnt > 0 ? bvh_leaf_ref(n.child[c], cnt) : n.child[c];
     }
 }
@@ -232,9 +259,10 @@ __device__ __forceinline__ void bvh_children(const BvhNode &n, V3 o, V3 inv_d, d
 /* closest hit through the hierarchy: min distance, lowest index on ties */
 __device__ __forceinline__ void bvh_closest(const SceneView &sv, V3 o, V3 d, double &min_dist, int &index)
 {
-    const V3 inv_d = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    const Ray32 r32 = bvh_ray32(o, d);
+    float lim = bvh_limit32(min_dist);
     int   stack[BVH_STACK];
-    float stack_t[BVH_STACK]; /* entry distance of the pushed subtree, rounded DOWN: a later, nearer hit culls it on pop */
+    float stack_t[BVH_STACK]; /* lower bound of the entry distance of the pushed subtree: a later, nearer hit culls it on pop */
     int sp = 0;
     int cur = 0;
     for (;;)
@@ -243,18 +271,15 @@ __device__ __forceinline__ void bvh_closest(const SceneView &sv, V3 o, V3 d, dou
         {
             const BvhNode &n = sv.bvh_nodes[cur];
             int ref[2];
-            double t[2];
+            float t[2];
             bool hit[2];
-            bvh_children(n, o, inv_d, min_dist, false, ref, t, hit);
+            bvh_children(n, r32, lim, ref, t, hit);
             if (hit[0] && hit[1])
             {
                 const int near = t[1] < t[0] ? 1 : 0; /* nearer box first */
-                if (sp < BVH_STACK)
-                {
-                    stack[sp] = ref[1 - near];
-                    stack_t[sp] = __double2float_rd(t[1 - near]);
-                    sp += 1;
-                }
+                stack[sp] = ref[1 - near]; /* sp < BVH_STACK: the builder refuses deeper trees (build_device_scene) */
+                stack_t[sp] = t[1 - near];
+                sp += 1;
                 cur = ref[near];
             }
             else if (hit[0]) cur = ref[0];
@@ -265,7 +290,7 @@ __device__ __forceinline__ void bvh_closest(const SceneView &sv, V3 o, V3 d, dou
                 while (sp > 0)
                 {
                     sp -= 1;
-                    if (!((double)stack_t[sp] > min_dist))
+                    if (!(stack_t[sp] > lim))
                     {
                         cur = stack[sp];
                         break;
@@ -286,13 +311,14 @@ __device__ __forceinline__ void bvh_closest(const SceneView &sv, V3 o, V3 d, dou
                 {
                     min_dist = dist;
                     index = (int)lp.index;
+                    lim = bvh_limit32(min_dist);
                 }
             }
             cur = BVH_DONE;
             while (sp > 0)
             {
                 sp -= 1;
-                if (!((double)stack_t[sp] > min_dist))
+                if (!(stack_t[sp] > lim))
                 {
                     cur = stack[sp];
                     break;
@@ -306,7 +332,8 @@ __device__ __forceinline__ void bvh_closest(const SceneView &sv, V3 o, V3 d, dou
 /* any surface nearer than vis_dist? (the shadow test; order does not matter for a yes/no answer) */
 __device__ __forceinline__ bool bvh_occluded(const SceneView &sv, V3 o, V3 d, double vis_dist)
 {
-    const V3 inv_d = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    const Ray32 r32 = bvh_ray32(o, d);
+    const float lim = bvh_limit32(vis_dist);
     int stack[BVH_STACK];
     int sp = 0;
     int cur = 0;
@@ -316,12 +343,12 @@ __device__ __forceinline__ bool bvh_occluded(const SceneView &sv, V3 o, V3 d, do
         {
             const BvhNode &n = sv.bvh_nodes[cur];
             int ref[2];
-            double t[2];
+            float t[2];
             bool hit[2];
-            bvh_children(n, o, inv_d, vis_dist, true, ref, t, hit);
+            bvh_children(n, r32, lim, ref, t, hit);
             if (hit[0] && hit[1])
             {
-                if (sp < BVH_STACK) stack[sp++] = ref[1];
+                stack[sp++] = ref[1];
                 cur = ref[0];
             }
             else if (hit[0]) cur = ref[0];

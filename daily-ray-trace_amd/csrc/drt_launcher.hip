@@ -170,6 +170,8 @@ struct BvhBuilder
     std::vector<BvhNode>   nodes;
     std::vector<uint32_t>  order;
     int LEAF = 2; /* surfaces per leaf (<= 8: the traversal packs the count in 3 bits) */
+    int max_depth = 0;    /* deepest level holding a node: the traversal pushes at most one entry per level */
+    double pad32 = 0.0;   /* extra padding of the STORED boxes that pays for testing them in f32 (drt_kernels.h, Ray32) */
 
     void bounds(size_t b, size_t e, double lo[3], double hi[3]) const
     {
@@ -186,8 +188,11 @@ struct BvhBuilder
     {
         double lo[3], hi[3];
         bounds(b, e, lo, hi);
+        max_depth = std::max(max_depth, depth + 1);
         for (int k = 0; k < 3; k += 1)
         {
+            lo[k] -= pad32;
+            hi[k] += pad32;
             /* outward to f32: the stored box must contain the (already padded) f64 box */
             float fl = (float)lo[k], fh = (float)hi[k];
             if ((double)fl > lo[k]) fl = std::nextafterf(fl, -INFINITY);
@@ -296,18 +301,27 @@ struct BvhBuilder
         set_child(node, 0, b, mid, depth);
         set_child(node, 1, mid, e, depth);
     }
-    void build(const drt_scene *scene)
+    /* `reach`: the largest |coordinate| a ray origin outside the surfaces can have (the camera) */
+    void build(const drt_scene *scene, double reach)
     {
+        double extent = reach;
         for (uint32_t i = 0; i < scene->num_surfaces; i += 1)
         {
             const drt_surface &s = scene->surfaces[i];
             if (s.type != DRT_GEO_SPHERE && s.type != DRT_GEO_PLANE) continue; /* points are never intersected */
             BuildPrim p;
             prim_bounds(s, p.lo, p.hi);
-            for (int k = 0; k < 3; k += 1) p.c[k] = 0.5 * (p.lo[k] + p.hi[k]);
+            for (int k = 0; k < 3; k += 1)
+            {
+                p.c[k] = 0.5 * (p.lo[k] + p.hi[k]);
+                if (std::fabs(p.lo[k]) < 1e299) extent = std::max(extent, std::fabs(p.lo[k]));
+                if (std::fabs(p.hi[k]) < 1e299) extent = std::max(extent, std::fabs(p.hi[k]));
+            }
             p.idx = i;
             prims.push_back(p);
         }
+        /* the f32 box test moves a slab plane by < 6 * 2^-24 * extent (drt_kernels.h, Ray32): pad by 2^-19 * extent, 5x that */
+        pad32 = std::ldexp(extent, -19);
         nodes.push_back(BvhNode());
         nodes[0].count[0] = nodes[0].count[1] = -1;
         nodes[0].child[0] = nodes[0].child[1] = 0;
@@ -317,7 +331,7 @@ struct BvhBuilder
     }
 };
 
-static int build_device_scene(drt_context *ctx, const drt_scene *scene)
+static int build_device_scene(drt_context *ctx, const drt_scene *scene, double reach)
 {
     const uint32_t S = scene->num_wavelengths;
     const uint32_t n_surf = scene->num_surfaces;
@@ -491,7 +505,9 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene)
     {
         BvhBuilder bb;
         if (const char *e = getenv("DRT_BVH_LEAF")) bb.LEAF = std::min(8, std::max(1, atoi(e))); /* tuning knob */
-        bb.build(scene);
+        bb.build(scene, reach);
+        /* the traversal stacks hold BVH_STACK entries, one per level at most, and push unchecked */
+        if (bb.max_depth > BVH_STACK) return fail(-2, "BVH of %zu surfaces is %d levels deep, the traversal stack holds %d", bb.prims.size(), bb.max_depth, BVH_STACK);
         std::vector<BvhLeafPrim> leaf(std::max<size_t>(bb.order.size(), 1));
         memset(leaf.data(), 0, leaf.size() * sizeof(BvhLeafPrim));
         for (size_t k = 0; k < bb.order.size(); k += 1)
@@ -572,6 +588,21 @@ static int shade_occupancy(drt_context *ctx, int *per_cu)
 
 extern "C" const char *drt_last_error(void) { return g_last_error.c_str(); }
 
+/* Host only (no HIP call): builds the hierarchy build_device_scene() would build and reports its shape. */
+extern "C" int drt_bvh_stats(const drt_scene *scene, uint32_t *nodes, uint32_t *leaf_surfaces, uint32_t *depth, uint32_t *stack_entries)
+{
+    g_last_error.clear();
+    if (!scene) return fail(-1, "null argument");
+    BvhBuilder bb;
+    if (const char *e = getenv("DRT_BVH_LEAF")) bb.LEAF = std::min(8, std::max(1, atoi(e)));
+    bb.build(scene, 0.0);
+    if (nodes) *nodes = (uint32_t)bb.nodes.size();
+    if (leaf_surfaces) *leaf_surfaces = (uint32_t)bb.order.size();
+    if (depth) *depth = (uint32_t)bb.max_depth;
+    if (stack_entries) *stack_entries = BVH_STACK;
+    return 0;
+}
+
 extern "C" int drt_device_count(void)
 {
     int n = 0;
@@ -600,7 +631,14 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
-    int rc = build_device_scene(ctx, scene);
+    /* ray origins that are not on a surface are on the camera: its aperture and its film */
+    double reach = 0.0;
+    for (int k = 0; k < 3; k += 1)
+    {
+        const double a = camera->aperture_position[k], f = camera->film_bottom_left[k];
+        reach = std::max(reach, std::fabs(a) + 2.0 * std::fabs(f - a) + std::fabs(camera->aperture_radius));
+    }
+    int rc = build_device_scene(ctx, scene, reach);
     if (rc) return rc;
 
     DevCamera &c = ctx->dcam;

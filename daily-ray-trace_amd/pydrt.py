@@ -322,6 +322,7 @@ def hip_lib():
                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(Stats)]
         L.drt_selftest_arith.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                          C.POINTER(C.c_double), C.c_uint64]
+        L.drt_bvh_stats.argtypes = [C.POINTER(Scene)] + [C.POINTER(C.c_uint32)] * 4
         L.drt_selftest_unit.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_double), C.c_uint32,
                                         C.c_uint64]
         _hip = L
@@ -331,7 +332,7 @@ def hip_lib():
 HIP_SYMBOLS = ["drt_last_error", "drt_device_count", "drt_create", "drt_destroy", "drt_bind_film", "drt_set_stream",
                "drt_render", "drt_synchronize", "drt_reset_film", "drt_film_device_ptrs", "drt_read_film", "drt_write_film",
                "drt_read_xyz", "drt_read_hit_indices", "drt_get_stats", "drt_batch_spp", "drt_render_tile", "drt_selftest_arith",
-               "drt_selftest_unit",
+               "drt_selftest_unit", "drt_bvh_stats",
                "drt_group_create", "drt_group_destroy", "drt_group_size", "drt_group_render", "drt_group_synchronize",
                "drt_group_read_film", "drt_group_write_film", "drt_group_get_stats", "drt_render_tile_multi"]
 
@@ -503,6 +504,13 @@ def selftest_arith(op, a, b=None, device=0):
 _UNIT_OUT = {UNIT_LINE_SPHERE: 1, UNIT_LINE_PLANE: 1, UNIT_REFLECT: 3, UNIT_TRANSMIT: 3, UNIT_ROTATION_BETWEEN: 9,
              UNIT_SAMPLE_SPHERE: 4, UNIT_SAMPLE_DISC: 4, UNIT_GGX: 1, UNIT_GGX_ATT: 1, UNIT_FS_DIELECTRIC: 1, UNIT_FS_CONDUCTOR: 1,
              UNIT_SEED_AND_DRAW: 2}
+
+
+def bvh_stats(bundle):
+    """(nodes, surfaces in leaves, levels, stack capacity) of the hierarchy the library builds for this scene; no GPU needed."""
+    v = [C.c_uint32() for _ in range(4)]
+    _check(hip_lib().drt_bvh_stats(C.byref(bundle.scene), *[C.byref(x) for x in v]), "drt_bvh_stats")
+    return tuple(x.value for x in v)
 
 
 def selftest_unit(func, records, device=0):

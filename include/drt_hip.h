@@ -262,6 +262,11 @@ int drt_render_tile_multi(const drt_scene *scene, const drt_camera *camera, cons
                           const int32_t *devices, uint32_t n_devices,
                           double *dst_pixels, double *dst_avgs, double *dst_vars, drt_stats *stats);
 
+/* Shape of the bounding-volume hierarchy drt_create() builds for scenes too large for LDS: node count, surfaces in
+ * leaves, levels, and the traversal stack's capacity in entries (one per level at most; drt_create() refuses a deeper tree).
+ * Host only: runs without a GPU. */
+int drt_bvh_stats(const drt_scene *scene, uint32_t *nodes, uint32_t *leaf_surfaces, uint32_t *depth, uint32_t *stack_entries);
+
 /* Arithmetic self-test kernels: evaluate op over n inputs on the device so tests can check
  * that f64 sqrt / divide / the path's sincos are bit-identical to the host. op: 0 sqrt(a),
  * 1 a/b, 2 sincos(a) -> out[2*i], out[2*i+1], 3 pow(a,b), 4 rng stream from key a (as u64 bits). */

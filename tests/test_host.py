@@ -299,3 +299,29 @@ def test_checkpoint_sets_are_crash_safe_and_resume_refuses_mixed_files(tmp_path)
     assert H.drt_host_read_spd(raw_path.encode(), C.create_string_buffer(40), C.byref(out)) != 0 and not out
     assert load(cfg)[0] != 0
     shutil.rmtree(short)
+
+
+def test_bvh_depth_stays_within_the_traversal_stack():
+    """the traversal pushes unchecked, one entry per level at most, so the BUILT tree's depth is what keeps it
+    safe. Host-side check (drt_bvh_stats builds the same tree drt_create would, no GPU needed) on the scenes that stress the
+    builder: the 10k-sphere config, collinear centres, thousands of identical surfaces (nothing for the SAH to separate),
+    and an exponential cluster (the SAH peels one surface per level until its level cap hands over to median splits)."""
+    def spheres(centres, radius=0.1):
+        surf = [{"type": pydrt.GEO_SPHERE, "material": 1, "position": [float(c[0]), float(c[1]), float(c[2])], "radius": radius} for c in centres]
+        mats = [{"is_black_body": 1}, {"diffuse_spd": 0, "bdsfs": [0], "dir_func": 0}]
+        cam = pydrt.init_camera([0, 0, 30], [0, 0, 0], 0.0, 60.0, 6.0, 0.3, 0.0, 8, 8)
+        return pydrt.build_scene(surf, mats, np.ones((4, 69)), 0, 0, cam)
+
+    rng = np.random.default_rng(5)
+    cases_ = {
+        "config 5": pydrt.synthetic_sphere_scene(10000, 8, 8),
+        "collinear": spheres(np.stack([np.linspace(-50, 50, 5000), np.zeros(5000), np.zeros(5000)], axis=1)),
+        "identical": spheres(np.zeros((3000, 3))),
+        "exponential": spheres(np.stack([2.0 ** -np.arange(0, 400, 0.25) * 40, rng.uniform(-1e-6, 1e-6, 1600), np.zeros(1600)], axis=1), radius=1e-9),
+    }
+    for name, bundle in cases_.items():
+        nodes, in_leaves, depth, stack = pydrt.bvh_stats(bundle)
+        n = sum(1 for i in range(int(bundle.scene.num_surfaces)) if bundle.scene.surfaces[i].type in (pydrt.GEO_SPHERE, pydrt.GEO_PLANE))
+        assert in_leaves == n, name                   # every surface is in exactly one leaf
+        assert 1 <= depth <= stack == 48, (name, depth)
+        assert nodes <= max(1, n), name
