@@ -188,7 +188,7 @@ __device__ __forceinline__ double surface_distance(const SceneView &sv, uint32_t
                       sv.surf[SF_ULEN * sv.n_surf + i], sv.surf[SF_VLEN * sv.n_surf + i]);
 }
 
-#define BVH_STACK 48
+#define BVH_STACK 32 /* levels of the deepest tree the builder hands out = entries a traversal stack can need */
 
 __device__ __forceinline__ double leaf_distance(const SceneView &sv, const BvhLeafPrim &lp, V3 o, V3 d)
 {

@@ -4,6 +4,7 @@
  * stream, HIP-event timing, statistics. gfx950 only; there is no CPU path in this library.
  */
 #include "drt_kernels.h"
+#include "drt_bvh_kernels.h"
 
 #include <algorithm>
 #include <cmath>
@@ -61,7 +62,11 @@ struct drt_context
     int32_t  *d_hits = nullptr;
     uint64_t  hits_capacity = 0; /* in paths */
     uint32_t  hits_samples = 0;
-    unsigned long long *d_counters = nullptr; /* DRT_NUM_COUNTERS stats + 1 work counter */
+    unsigned long long *d_counters = nullptr; /* DRT_NUM_COUNTERS stats, then per kernel pair: trace queue, shade queue, bounce queue length, spare */
+    PrimaryHit *d_primary = nullptr;          /* BVH pipeline: closest hit of every path's camera ray (drt_bvh_kernels.h) */
+    uint64_t   *d_queue = nullptr;            /* BVH pipeline: ids of the paths that go on after their first hit */
+    bool        bvh_pipeline = false;
+    int         primary_grid_cap = 0, bounce_grid_cap = 0;
     double   *d_xyz = nullptr;
 
     bool   scene_in_lds = true, spds_in_lds = true, use_bvh = false;
@@ -233,9 +238,12 @@ struct BvhBuilder
             }
         int best_axis = -1, best_bin = -1;
         double best_cost = HUGE_VAL;
-        /* SAH trees have no depth bound of their own; the traversal stack holds BVH_STACK (48) entries, one per level at most:
-         * below level 24 the median split takes over, which adds at most log2(n) levels */
-        if (!getenv("DRT_BVH_MEDIAN") && depth < 24)
+        /* SAH trees have no depth bound of their own, and the traversal stacks hold BVH_STACK entries, one per level at most.
+         * A median-split subtree over m surfaces is at most 1 + ceil(log2 m) levels deep, so the SAH may split this node only
+         * while a median-split subtree below its children would still fit. */
+        int log2m = 0;
+        while (((size_t)1 << log2m) < e - b) log2m += 1;
+        if (!getenv("DRT_BVH_MEDIAN") && depth + 2 + log2m < BVH_STACK)
             for (int axis = 0; axis < 3; axis += 1)
             {
                 double ext = chi[axis] - clo[axis];
@@ -683,7 +691,8 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
         shade_sets(S, &sets, &tf, &tc);
         ctx->tail_count = tc;
     }
-    const size_t slot_bytes = (size_t)ctx->path_words * 8 + REC_HEADER_WORDS * 8 + (size_t)ctx->tail_count * 8;
+    const size_t slot_bytes = (size_t)ctx->path_words * 8 + REC_HEADER_WORDS * 8 + (size_t)ctx->tail_count * 8 +
+                              ((ctx->use_bvh && ctx->dsc.bvh_nodes) ? sizeof(PrimaryHit) + sizeof(uint64_t) : 0);
     while (batch > 1 && (size_t)ctx->n_pix * batch * slot_bytes + film_bytes > free_b / 2) batch /= 2;
     ctx->batch_spp = batch;
     size_t rec_bytes = (size_t)ctx->n_pix * batch * ctx->path_words * 8;
@@ -691,6 +700,13 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
         return fail(-3, "not enough device memory: need %zu bytes", (size_t)ctx->n_pix * batch * slot_bytes + film_bytes);
     HIP_TRY(hipMalloc((void **)&ctx->d_records, rec_bytes));
     HIP_TRY(hipMalloc((void **)&ctx->d_headers, (size_t)ctx->n_pix * batch * REC_HEADER_WORDS * 8));
+    /* scenes behind the hierarchy: camera rays walk it a wave at a time, the rest of each path runs from a queue (drt_bvh_kernels.h) */
+    ctx->bvh_pipeline = ctx->use_bvh && ctx->dsc.bvh_nodes && !getenv("DRT_BVH_ONE_KERNEL");
+    if (ctx->bvh_pipeline)
+    {
+        HIP_TRY(hipMalloc((void **)&ctx->d_primary, (size_t)ctx->n_pix * batch * sizeof(PrimaryHit)));
+        HIP_TRY(hipMalloc((void **)&ctx->d_queue, (size_t)ctx->n_pix * batch * sizeof(uint64_t)));
+    }
 
     HIP_TRY(hipMalloc((void **)&ctx->d_pixels, pixels_bytes(ctx)));
     if (!ctx->xyz_mode)
@@ -702,8 +718,8 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     HIP_TRY(hipMemsetAsync(ctx->d_pixels, 0, pixels_bytes(ctx), ctx->stream));
     if (ctx->d_avgs) HIP_TRY(hipMemsetAsync(ctx->d_avgs, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
     if (ctx->d_vars) HIP_TRY(hipMemsetAsync(ctx->d_vars, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
-    HIP_TRY(hipMalloc((void **)&ctx->d_counters, (DRT_NUM_COUNTERS + 2) * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 2) * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMalloc((void **)&ctx->d_counters, (DRT_NUM_COUNTERS + 4) * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 4) * sizeof(unsigned long long), ctx->stream));
 
     /* persistent trace grid: as many workgroups as the chip keeps resident */
     hipDeviceProp_t prop;
@@ -716,6 +732,15 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     if (per_cu < 1) per_cu = 1;
     if (const char *e = getenv("DRT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e)); /* tuning knob */
     ctx->trace_grid_cap = prop.multiProcessorCount * per_cu;
+    if (ctx->bvh_pipeline)
+    {
+        int p_cu = 0, b_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p_cu, drt_primary_kernel, PRIMARY_BLOCK, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_cu, drt_bounce_kernel, BOUNCE_BLOCK, 0));
+        if (const char *e = getenv("DRT_TRACE_BLOCKS_PER_CU")) b_cu = std::max(1, atoi(e));
+        ctx->primary_grid_cap = prop.multiProcessorCount * std::max(1, p_cu);
+        ctx->bounce_grid_cap = prop.multiProcessorCount * std::max(1, b_cu);
+    }
     /* shade kernel LDS: SPD tables + two record buffers per wave */
     ctx->shade_lds = ctx->spds_in_lds ? (size_t)ctx->dsc.n_spd * S * 8 : 0;
     int s_per_cu = 0;
@@ -781,6 +806,8 @@ extern "C" void drt_destroy(drt_context *ctx)
     }
     (void)hipFree(ctx->d_records);
     (void)hipFree(ctx->d_headers);
+    (void)hipFree(ctx->d_primary);
+    (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_tail_stage);
     (void)hipFree(ctx->d_hits);
     (void)hipFree(ctx->d_counters);
@@ -894,9 +921,10 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
         int rc = next_events(ctx, ev);
         if (rc) return rc;
         unsigned long long *work = ctx->d_counters + DRT_NUM_COUNTERS;
-        HIP_TRY(hipMemsetAsync(work, 0, 2 * sizeof(unsigned long long), ctx->stream)); /* trace + shade work queues */
+        HIP_TRY(hipMemsetAsync(work, 0, 4 * sizeof(unsigned long long), ctx->stream)); /* trace + shade work queues, bounce queue length */
         uint64_t blocks_needed = (tp.n_paths + TRACE_BLOCK - 1) / TRACE_BLOCK;
-        uint32_t grid = (uint32_t)std::min<uint64_t>(blocks_needed, (uint64_t)ctx->trace_grid_cap);
+        const int grid_cap = ctx->bvh_pipeline ? ctx->bounce_grid_cap : ctx->trace_grid_cap;
+        uint32_t grid = (uint32_t)std::min<uint64_t>(blocks_needed, (uint64_t)grid_cap);
         /* work-queue granularity: about 16 draws per wave, so that the last draws finish together; 64..1024 path ids */
         {
             uint64_t waves = (uint64_t)grid * (TRACE_BLOCK / 64);
@@ -905,7 +933,18 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
             if (ctx->trace_chunk_override) tp.chunk = ctx->trace_chunk_override;
         }
         HIP_TRY(hipEventRecord(ev[0], ctx->stream));
-        if (ctx->scene_in_lds)
+        if (ctx->bvh_pipeline)
+        {
+            /* camera rays: a wave per 64 path ids; then the queued paths, one per lane */
+            const uint64_t packets = (tp.n_paths + 63) / 64;
+            const uint32_t pgrid = (uint32_t)std::min<uint64_t>((packets + PRIMARY_BLOCK / 64 - 1) / (PRIMARY_BLOCK / 64), (uint64_t)ctx->primary_grid_cap);
+            hipLaunchKernelGGL(drt_primary_kernel, dim3(pgrid), dim3(PRIMARY_BLOCK), 0, ctx->stream, ctx->dsc, ctx->dcam, tp, ctx->d_headers,
+                               ctx->d_hits, ctx->d_counters, ctx->d_primary, ctx->d_queue, work + 2);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(drt_bounce_kernel, dim3(grid), dim3(BOUNCE_BLOCK), 0, ctx->stream, ctx->dsc, ctx->dcam, tp, ctx->d_records,
+                               ctx->d_headers, ctx->d_hits, ctx->d_counters, work, ctx->d_primary, ctx->d_queue, work + 2);
+        }
+        else if (ctx->scene_in_lds)
             hipLaunchKernelGGL(drt_trace_kernel<true>, dim3(grid), dim3(TRACE_BLOCK), ctx->trace_lds, ctx->stream, ctx->dsc,
                                ctx->dcam, tp, ctx->d_records, ctx->d_headers, ctx->d_hits, ctx->d_counters, work);
         else
@@ -994,7 +1033,7 @@ extern "C" int drt_reset_film(drt_context *ctx)
     HIP_TRY(hipMemsetAsync(ctx->d_pixels, 0, pixels_bytes(ctx), ctx->stream));
     if (ctx->d_avgs) HIP_TRY(hipMemsetAsync(ctx->d_avgs, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
     if (ctx->d_vars) HIP_TRY(hipMemsetAsync(ctx->d_vars, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 2) * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 4) * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->trace_ms = ctx->shade_ms = 0.0;
     return 0;

@@ -323,5 +323,5 @@ def test_bvh_depth_stays_within_the_traversal_stack():
         nodes, in_leaves, depth, stack = pydrt.bvh_stats(bundle)
         n = sum(1 for i in range(int(bundle.scene.num_surfaces)) if bundle.scene.surfaces[i].type in (pydrt.GEO_SPHERE, pydrt.GEO_PLANE))
         assert in_leaves == n, name                   # every surface is in exactly one leaf
-        assert 1 <= depth <= stack == 48, (name, depth)
+        assert 1 <= depth <= stack == 32, (name, depth)
         assert nodes <= max(1, n), name
