@@ -165,6 +165,7 @@ __global__ __launch_bounds__(PRIMARY_BLOCK) void drt_primary_kernel(DevScene sc,
                 for (int k = 0; k < count; k += 1)
                 {
                     const BvhLeafPrim &lp = sv.bvh_leaf[first + k];
+                    if (!__any(valid && !sphere_certainly_missed(lp, r32, lim))) continue; /* no lane's ray comes near it */
                     double dist = leaf_distance(sv, lp, o, rd);
                     if (valid && (dist < min_dist || (dist == min_dist && (int)lp.index < index)))
                     {
@@ -275,6 +276,7 @@ __device__ __forceinline__ void bvh_walk(const SceneView &sv, int *stack, uint32
             for (int k = 0; k < count; k += 1)
             {
                 const BvhLeafPrim &lp = sv.bvh_leaf[first + k];
+                if (sphere_certainly_missed(lp, r32, lim)) continue;
                 double dist = leaf_distance(sv, lp, o, d);
                 if (job == JOB_CLOSEST)
                 {

@@ -71,7 +71,9 @@ struct BvhLeafPrim
 {
     uint32_t index, type;
     double   f[4]; /* a sphere's centre and radius; a plane's many fields are read from the SoA tables (planes are few) */
-    double   pad[3];
+    float    c32[3];  /* the centre again in f32, and the radius plus the f32 test's error bound, rounded up (planes: 0 and +inf): */
+    float    reach32; /* sphere_certainly_missed() spares the f64 intersector most of the spheres a ray passes by */
+    double   pad;
 };             /* 64 bytes */
 
 struct DevMaterial
@@ -206,6 +208,7 @@ __device__ __forceinline__ double leaf_distance(const SceneView &sv, const BvhLe
 struct Ray32
 {
     float ix, iy, iz, nx, ny, nz; /* 1/d and -o/d */
+    float ox, oy, oz, dx, dy, dz; /* o and d */
 };
 __device__ __forceinline__ Ray32 bvh_ray32(V3 o, V3 d)
 {
@@ -216,7 +219,25 @@ __device__ __forceinline__ Ray32 bvh_ray32(V3 o, V3 d)
     r.nx = -((float)o.x * r.ix);
     r.ny = -((float)o.y * r.iy);
     r.nz = -((float)o.z * r.iz);
+    r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
+    r.dx = (float)d.x; r.dy = (float)d.y; r.dz = (float)d.z;
     return r;
+}
+
+/* A sphere the ray certainly does not hit within `lim`: its centre is farther from the ray's line than radius + bound, or it
+ * lies wholly behind the origin, or wholly beyond the limit. All in f32; with u = 2^-24 and E the largest coordinate, the
+ * rounding of centre, origin, direction and the three fused dot products moves the foot point by < 40 u E and the distance
+ * along the ray by < 17 u E; reach32 = radius + 64 u E (rounded up) pays for both, so whenever this says "missed" the f64
+ * intersector (line_sphere) would have returned no hit, or one beyond `lim`, and skipping it changes no result. Anything
+ * not finite compares false: not skipped. */
+__device__ __forceinline__ bool sphere_certainly_missed(const BvhLeafPrim &lp, const Ray32 &r, float lim)
+{
+    const float cx = lp.c32[0] - r.ox, cy = lp.c32[1] - r.oy, cz = lp.c32[2] - r.oz;
+    const float t = __builtin_fmaf(cz, r.dz, __builtin_fmaf(cy, r.dy, cx * r.dx));
+    const float px = __builtin_fmaf(-t, r.dx, cx), py = __builtin_fmaf(-t, r.dy, cy), pz = __builtin_fmaf(-t, r.dz, cz);
+    const float p2 = __builtin_fmaf(pz, pz, __builtin_fmaf(py, py, px * px));
+    const float R = lp.reach32;
+    return p2 > R * R || t + R < 0.0f || t - R > lim;
 }
 /* a distance limit for f32 comparisons, rounded UP (inf stays inf, 0 stays 0) */
 __device__ __forceinline__ float bvh_limit32(double limit) { return (float)limit * 1.00000024f; }

@@ -174,9 +174,10 @@ struct BvhBuilder
     std::vector<BuildPrim> prims;
     std::vector<BvhNode>   nodes;
     std::vector<uint32_t>  order;
-    int LEAF = 2; /* surfaces per leaf (<= 8: the traversal packs the count in 3 bits) */
+    int LEAF = 1; /* surfaces per leaf (<= 8: the traversal packs the count in 3 bits). Config 5, trace stage: 757 ms with 1, 855 with 2, 948 with 4 */
     int max_depth = 0;    /* deepest level holding a node: the traversal pushes at most one entry per level */
     double pad32 = 0.0;   /* extra padding of the STORED boxes that pays for testing them in f32 (drt_kernels.h, Ray32) */
+    double extent = 0.0;  /* largest |coordinate| of the surfaces' boxes and of the camera */
 
     void bounds(size_t b, size_t e, double lo[3], double hi[3]) const
     {
@@ -312,7 +313,7 @@ struct BvhBuilder
     /* `reach`: the largest |coordinate| a ray origin outside the surfaces can have (the camera) */
     void build(const drt_scene *scene, double reach)
     {
-        double extent = reach;
+        extent = reach;
         for (uint32_t i = 0; i < scene->num_surfaces; i += 1)
         {
             const drt_surface &s = scene->surfaces[i];
@@ -524,6 +525,14 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene, double r
             leaf[k].index = i;
             leaf[k].type = stype[i];
             for (int f = 0; f < 4; f += 1) leaf[k].f[f] = surf[(size_t)f * n_surf + i]; /* SF_PX, SF_PY, SF_PZ, SF_RADIUS */
+            leaf[k].reach32 = INFINITY; /* planes: never "certainly missed" */
+            if (stype[i] == DRT_GEO_SPHERE)
+            {
+                for (int f = 0; f < 3; f += 1) leaf[k].c32[f] = (float)leaf[k].f[f];
+                /* radius + 64 u E (drt_kernels.h, sphere_certainly_missed), rounded up twice over */
+                float reach = (float)(std::fabs(leaf[k].f[3]) + std::ldexp(bb.extent, -18));
+                leaf[k].reach32 = std::nextafterf(std::nextafterf(reach, INFINITY), INFINITY);
+            }
         }
         if ((rc = upload(ctx, bb.nodes, &d.bvh_nodes))) return rc;
         if ((rc = upload(ctx, leaf, &d.bvh_leaf))) return rc;
@@ -929,7 +938,7 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
         {
             uint64_t waves = (uint64_t)grid * (TRACE_BLOCK / 64);
             uint64_t c = tp.n_paths / (waves * 16) / 64 * 64;
-            tp.chunk = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c, 64), 1024);
+            tp.chunk = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c, 64), ctx->bvh_pipeline ? 256 : 1024); /* queued paths all cost alike: small draws (config 5: 827 ms at 64-256, 855 at 1024) */
             if (ctx->trace_chunk_override) tp.chunk = ctx->trace_chunk_override;
         }
         HIP_TRY(hipEventRecord(ev[0], ctx->stream));
