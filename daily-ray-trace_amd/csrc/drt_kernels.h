@@ -1059,6 +1059,9 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
 #ifndef SHADE_PREFETCH_DEPTH
 #define SHADE_PREFETCH_DEPTH 2 /* samples whose record loads are in flight ahead of the one being replayed */
 #endif
+#ifndef DRT_SHADE_LDS_WORDS
+#define DRT_SHADE_LDS_WORDS 1 /* plastic vertices read their coefficient words from LDS (broadcast loads) instead of v_readlane pairs */
+#endif
 #define SHADE_PIXEL_CHUNK 16 /* pixels per group when there is no tail pass (with one: 64 / tail wavelengths) */
 
 #define XYZ_FILM_WORDS 8 /* XYZ film mode, per pixel: X, Y, Z numerators of the main pass, filter sum, X, Y, Z of the tail pass, unused */
@@ -1267,6 +1270,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
+#if DRT_SHADE_LDS_WORDS
+    /* behind the SPD table: two record slots per wave (see the sample loop) */
+    uint64_t *rec_lds = (uint64_t *)(lds + (SPDS_IN_LDS ? (size_t)sc.n_spd * S : 0)) + (size_t)(threadIdx.x >> 6) * (2u * 64u * SHADE_PREFETCH_REGS);
+#endif
     const uint32_t vw = sp.vertex_words;                 /* power of two >= 16 */
     const uint32_t vpr = vw <= 64 ? 64u / vw : 0u;       /* vertices per 64-word register (0: records wider than a register) */
     const uint32_t n_fast = vpr * SHADE_PREFETCH_REGS;   /* vertices covered by the prefetch registers */
@@ -1395,6 +1402,22 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
                 for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) ring[SHADE_PREFETCH_DEPTH][k] = (64u * k + lane < nw) ? p[64u * k + lane] : 0;
             }
             const uint64_t *cur = ring[0];
+#if DRT_SHADE_LDS_WORDS
+            /* The records of the sample AFTER this one (requested a sample ago) go to this wave's LDS slot (s + 1) & 1: the
+             * coefficient words of a plastic vertex are then read back as broadcast LDS loads -- one instruction per 64-bit word,
+             * result in a vector register where the f64 operations want it -- instead of two v_readlane each. */
+            {
+                uint64_t *slot_next = rec_lds + ((s + 1u) & 1u) * (64u * SHADE_PREFETCH_REGS);
+#pragma unroll
+                for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) slot_next[64u * k + lane] = ring[1][k];
+                if (s == 0)
+                {
+#pragma unroll
+                    for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) rec_lds[64u * k + lane] = ring[0][k];
+                }
+            }
+            const uint64_t *rec_words = rec_lds + (s & 1u) * (64u * SHADE_PREFETCH_REGS);
+#endif
 
             double throughput[NSETS], dst[NSETS];
 #pragma unroll
@@ -1445,8 +1468,13 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
                             if ((vis0_mask >> v) & 1u)
                             {
                                 const uint32_t off = REC_VERTEX_WORDS;
+#if DRT_SHADE_LDS_WORDS
+                                const uint64_t *lw = rec_words + v * vw + off;
+                                const double c = word_as_double(lw[1]), a_in = word_as_double(lw[2]), spec = word_as_double(lw[3]);
+#else
                                 const double c = word_as_double(readlane64(src, lane0 + off + 1));
                                 const double a_in = word_as_double(readlane64(src, lane0 + off + 2)), spec = word_as_double(readlane64(src, lane0 + off + 3));
+#endif
 #pragma unroll
                                 for (int k = 0; k < NSETS; k += 1)
                                 {
@@ -1501,6 +1529,14 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
                 if (v < 16u && ((plastic_mask >> v) & 1u))
                 {
                     const uint64_t w1p = readlane64(src, lane0 + 1);
+#if DRT_SHADE_LDS_WORDS
+                    if (v < n_fast)
+                    {
+                        const uint64_t *vwords = rec_words + v * vw;
+                        plastic_vertex(w1p, word_as_double(vwords[4]), word_as_double(vwords[5]), word_as_double(vwords[6]));
+                        continue;
+                    }
+#endif
                     const double dir_pdf_p = word_as_double(readlane64(src, lane0 + 4));
                     const double s_a_in_p = word_as_double(readlane64(src, lane0 + 5)), s_spec_p = word_as_double(readlane64(src, lane0 + 6));
                     plastic_vertex(w1p, dir_pdf_p, s_a_in_p, s_spec_p);

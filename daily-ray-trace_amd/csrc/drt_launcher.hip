@@ -752,6 +752,7 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     }
     /* shade kernel LDS: SPD tables + two record buffers per wave */
     ctx->shade_lds = ctx->spds_in_lds ? (size_t)ctx->dsc.n_spd * S * 8 : 0;
+    if (DRT_SHADE_LDS_WORDS) ctx->shade_lds += (size_t)SHADE_WAVES * 2 * 64 * SHADE_PREFETCH_REGS * 8; /* two record slots per wave */
     int s_per_cu = 0;
     shade_sets(S, &ctx->shade_sets, &ctx->tail_first, &ctx->tail_count);
     if (ctx->tail_count) HIP_TRY(hipMalloc((void **)&ctx->d_tail_stage, (size_t)ctx->n_pix * ctx->batch_spp * ctx->tail_count * 8));
