@@ -597,7 +597,7 @@ def test_bench_two_rank_rehearsal_assembles_the_same_frame():
     import sys
     pytest.importorskip("torch")
     bench = os.path.join(cases.REPO, "bench.py")
-    common = ["--size", "96", "--spp", "6", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--checksum"]
+    common = ["--size", "96", "--spp", "6", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-oneshot", "--checksum"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
 
     def last_json(cmd):
