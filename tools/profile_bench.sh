@@ -6,7 +6,7 @@ TAG=${1:-r02}
 OUT=$PWD/gpurun_out/prof_bench_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python3 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline"
+CMD="python3 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-oneshot"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || echo "trace pass failed"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1 || echo "fetch failed"
 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.log 2>&1 || echo "write failed"
