@@ -348,7 +348,10 @@ def main():
         for r in live:
             r.synchronize()
         sts = [r.stats() for r in live]
-        return {k: sum(getattr(st, k) for st in sts) for k in ("paths", "trace_ms", "shade_ms", "closest_hit_scans", "shaded_vertices")}
+        out = {k: sum(getattr(st, k) for st in sts) for k in ("paths", "trace_ms", "shade_ms", "closest_hit_scans", "shaded_vertices", "redone_launches")}
+        out["pool_bytes"] = sum(st.record_pool_blocks * st.record_block_bytes for st in sts)
+        out["pool_peak_bytes"] = max(st.record_pool_peak * st.record_block_bytes for st in sts)
+        return out
 
     if world > 1:
         # set up the communicator and its point-to-point connections (made lazily on first use) outside the timed region,
@@ -388,12 +391,15 @@ def main():
         dominant = "shade" if shade_ms >= trace_ms else "trace"
         # per launch: paths per kernel launch and its average duration (launches = batches)
         paths_per_launch = batch_spp * block_pixels
+        paths_per_launch_all = batch_spp * sum(fb.rows for fb in blocks) * W  # this rank's launches side by side (one context per row block)
         launches = max(1, round(paths_rank / max(paths_per_launch, 1)))
         kernel_ms = {"trace": trace_ms, "shade": shade_ms}
         roof = roofline(dominant, kernel_ms, launches, paths_per_launch, model,
                         "cornell_plane_light %dx%d depth %d" % (W, H, args.depth), xyz)
         roof.update({"kernel_ms_per_step": {"trace": round(trace_ms / args.steps, 3), "shade": round(shade_ms / args.steps, 3)},
                      "v_int": round(v_int, 4), "v_shade": round(v_shade, 4)})
+        if st1["redone_launches"]:
+            raise SystemExit("bench.py: %d launches ran out of record blocks and were rendered again: the timing is not the path's" % st1["redone_launches"])
         out = {
             "metric": "Mpaths/s (pixels*spp/s) Cornell 1024^2 depth 8; achieved HBM GB/s % of peak" + (" [XYZ-only film: NOT the headline mode]" if xyz else ""),
             "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -404,7 +410,9 @@ def main():
                                 "full spectral (sum+filter, mean, variance x %d wavelengths)" % S),
                        "partition": ("whole frame on one GPU" if world == 1 and len(blocks) == 1 else
                                      "rows cyclic over %d rank(s) in %d row block(s); each block's film gathered to rank 0 while the next renders" % (world, len(blocks))),
-                       "paths_per_step": W * H * args.spp},
+                       "paths_per_step": W * H * args.spp,
+                       "record_pool_GB": round(st1["pool_bytes"] / 1e9, 2), "record_pool_peak_GB": round(st1["pool_peak_bytes"] / 1e9, 2),
+                       "record_pool_worst_case_GB": round(paths_per_launch_all * args.depth * 128 / 1e9, 2)},
             "roofline": roof,
         }
         if world > 1:

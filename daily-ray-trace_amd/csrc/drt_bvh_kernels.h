@@ -108,6 +108,7 @@ __global__ __launch_bounds__(PRIMARY_BLOCK) void drt_primary_kernel(DevScene sc,
     const uint64_t wave0 = (uint64_t)blockIdx.x * (PRIMARY_BLOCK / 64) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (PRIMARY_BLOCK / 64);
     uint32_t n_scans = 0, n_draws = 0, n_paths = 0;
+    if (*tp.overflow) return; /* an earlier launch ran out of record blocks: the host renders from there again */
 
     for (uint64_t packet = wave0; packet < n_packets; packet += n_waves)
     {
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
     sv.bvh_nodes = sc.bvh_nodes; sv.bvh_leaf = sc.bvh_leaf;
     const uint32_t lane = threadIdx.x & 63u;
     int *stack = s_stack[threadIdx.x >> 6];
+    if (*tp.overflow) return;
     const uint64_t n_work = *queue_count;
     const uint64_t CHUNK = tp.chunk;
     uint64_t chunk_next = 0, chunk_end = 0; /* wave-uniform */
@@ -328,7 +330,11 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
     uint32_t depth = 0, shaded = 0, light = 0;
     uint32_t vis0_mask = 0, plastic_mask = 0;
     V3 ro = v3(0, 0, 0), rd = v3(0, 0, 0);
-    uint64_t *rec = nullptr, *hdr = nullptr;
+    uint64_t *hdr = nullptr;
+    uint32_t blk = 0, tbl = 0; /* the pool block of the current pair of vertices; the path's table block (deep paths) */
+    uint32_t spare = ~0u, spare_tbl = ~0u; /* a block (and, for deep paths, a table block) held ready: path_spare_block */
+    bool new_vertex = false;   /* the path has arrived at a vertex and nothing of it is written yet: its first record opens it */
+    WavePool wp = {0u, 0u, 0u};
     HitPoint ip;
     ip.position = ip.normal = ip.out = v3(0, 0, 0);
     ip.on_dot = 0.0;
@@ -382,7 +388,6 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
                 rs = drt_splitmix64(path_key(tp, ps));
                 uint32_t camera_draws = 0; /* counted by the primary kernel */
                 camera_ray(cam, tp.pixel_scheme, ps.x, ps.y, rs, camera_draws, ro, rd);
-                rec = records + ps.slot * (uint64_t)tp.path_words;
                 hdr = headers + ps.slot * REC_HEADER_WORDS;
                 const PrimaryHit ph = primary[ps.slot];
                 hit_point_from_scan(sv, sc, ip, v_sum(ro, v_mul(rd, DRT_VIS_FUDGE)), rd, ph.min_dist, ph.index);
@@ -393,10 +398,17 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
                 vis0_mask = 0;
                 alive = true;
                 at_vertex = true;
+                new_vertex = true;
                 n_shaded += 1; /* direct_light_contribution is entered for this vertex */
             }
         }
         if (!__any(alive)) break;
+        /* a spare record block for the lanes whose path may open one at its next vertex (the whole wave takes part) */
+        if (!path_spare_block(tp, wp, alive, shaded, spare, spare_tbl, lane))
+        {
+            hdr[0] = (uint64_t)HDR_TERM_NOT_DONE << 16;
+            alive = false;
+        }
 
         /* ---- one traversal job per lane ---- */
         int job = JOB_NONE;
@@ -471,6 +483,7 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
             else
             {
                 at_vertex = true;
+                new_vertex = true;
                 light = 0;
                 n_shaded += 1;
             }
@@ -478,7 +491,12 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
         else if (job == JOB_SHADOW)
         {
             const uint32_t l = light;
-            uint64_t *vrec = rec + (uint64_t)shaded * tp.vertex_words;
+            if (new_vertex)
+            {
+                path_open_vertex(tp, wp, records, shaded, hdr, blk, tbl, spare, spare_tbl);
+                new_vertex = false;
+            }
+            uint64_t *vrec = records + (uint64_t)blk * tp.block_words + (uint64_t)(shaded & (REC_BLOCK_VERTICES - 1u)) * tp.vertex_words;
             uint64_t *lrec = vrec + REC_VERTEX_WORDS + (uint64_t)l * REC_LIGHT_WORDS;
             uint32_t lflags = 0;
             if (!occluded)
@@ -498,8 +516,13 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
         if (alive && at_vertex && light >= sv.n_lights)
         {
             /* every light is done (or there is none): the sampled continuation, :464-472 */
+            if (new_vertex)
+            {
+                path_open_vertex(tp, wp, records, shaded, hdr, blk, tbl, spare, spare_tbl);
+                new_vertex = false;
+            }
             const DevMaterial &mat = sv.mats[ip.surface_mat];
-            uint64_t *vrec = rec + (uint64_t)shaded * tp.vertex_words;
+            uint64_t *vrec = records + (uint64_t)blk * tp.block_words + (uint64_t)(shaded & (REC_BLOCK_VERTICES - 1u)) * tp.vertex_words;
             V3 in;
             double dir_pdf;
             sample_direction(sc, sv, ip, rs, n_draws, in, dir_pdf);
@@ -527,8 +550,8 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
         }
     }
 
-    uint64_t vals[5] = {0, n_scans, n_shaded, n_shadow, n_draws};
-    for (int k = 1; k < 5; k += 1)
+    uint64_t vals[6] = {0, n_scans, n_shaded, n_shadow, n_draws, wp.taken};
+    for (int k = 1; k < 6; k += 1)
     {
         uint64_t v = vals[k];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);

@@ -115,12 +115,22 @@ struct DevCamera
 /* ---------------------------------------------------------------------------------------------- */
 /* Vertex records (trace -> shade). All 8-byte words; self-contained, so the shade kernel never  */
 /* looks a material up: the trace kernel resolves it into a packed BDSF list + SPD indices.        */
-/* Records of one pixel's samples are contiguous: path slot = pixel * batch + sample_in_batch.     */
 /*                                                                                                  */
-/*  path header (2 words, own array):                                                              */
+/* Records live in a POOL of blocks of four vertices (4 * vertex_words words). A path takes a block */
+/* when it reaches its 1st, 5th, 9th ... vertex -- one atomic add per wave and loop iteration, the  */
+/* lanes' shares by ballot + prefix count (pool_alloc) -- so the pool holds what paths really use   */
+/* (1.65 of 8 possible vertices on the Cornell frame) instead of max_depth slots per path. The     */
+/* path's header says where its blocks are. A pool that runs out raises `overflow`: the shade       */
+/* kernel of that launch and everything queued behind it become no-ops, and the host renders those  */
+/* samples again with launches sized for the worst case (drt_launcher.hip, redo_batches).           */
+/*                                                                                                  */
+/*  path header (4 words, own array, indexed by slot = pixel * batch + sample_in_batch):           */
 /*     w0 = n_shaded (bits 0-15) | term (16-23: 0 none/escape, 1 emissive hit) | light 0 visible from vertex v < 8 (24-31) |
  *          emission SPD (32-47) | vertex v < 16 has the two-lobe plastic list (48-63)                                      */
 /*     w1 = vignette (double)                                                                      */
+/*     w2 = block of vertices 0-3 (bits 0-31) | block of vertices 4-7 (32-63)                       */
+/*     w3 = block of vertices 8-11 (bits 0-31) | TABLE block (32-63): a pool block used as an array */
+/*          of 32-bit block numbers for vertices 12-15, 16-19, ... (deep paths only)                */
 /*  vertex fixed part (10 words):                                                                  */
 /*     w0 = BDSF list, 4 bits per entry (the material's bdsfs[] in order)                          */
 /*     w1 = num_bdsfs (0-7) | sampled-direction flags (8-15) | diffuse SPD (16-31) | glossy SPD (32-47) | mirror SPD (48-63) */
@@ -135,7 +145,11 @@ struct DevCamera
 /*  per diffuse SPD (w1's "diffuse" field points at it), then one all-zero row that stands for a   */
 /*  missing spectrum (NULL in the reference).                                                       */
 
-#define REC_HEADER_WORDS 2
+#define REC_HEADER_WORDS 4
+#define REC_BLOCK_SHIFT 2   /* log2 of the vertices per pool block: four, what one 64-word prefetch register of the shade kernel holds at 16 words per vertex */
+#define REC_BLOCK_VERTICES (1u << REC_BLOCK_SHIFT)
+#define REC_HEADER_BLOCKS 3 /* blocks named in the header itself; further ones through the table block */
+#define HDR_TERM_NOT_DONE 0x80u /* header `term` byte of a path that found the pool exhausted */
 #define REC_VERTEX_WORDS 10
 #define REC_LIGHT_WORDS 6
 #define FLAG_EQR 1u
@@ -149,10 +163,93 @@ struct TraceParams
     uint32_t first_sample, n_samples, max_depth, pixel_scheme, record_hits;
     uint64_t seed;
     uint64_t n_pix, n_paths;
-    uint32_t vertex_words, path_words; /* record strides in 8-byte words (path_words = max_depth * vertex_words) */
-    uint32_t hits_sample_offset, batch;  /* batch = sample slots per pixel in the record arrays */
-    uint32_t chunk, pad0;                /* path ids a wave draws from the work counter at a time (multiple of 64) */
+    uint32_t vertex_words, block_words; /* a vertex record and a pool block (four vertices) in 8-byte words */
+    uint32_t hits_sample_offset, batch;  /* batch = sample slots per pixel in the header array */
+    uint32_t chunk, pool_blocks;         /* path ids a wave draws from the work counter at a time (multiple of 64); blocks in the pool */
+    unsigned long long *pool_cursor;     /* next free block of the pool (reset before every trace launch) */
+    uint32_t *overflow;                  /* set when the pool ran out: this launch's records are incomplete */
 };
+
+/* A wave's share of the pool. Waves take POOL_CHUNK blocks at a time from the global cursor and hand them to their lanes by
+ * ballot + prefix count: one atomic per ~250 blocks instead of one per loop iteration (a single word takes 100-200 atomics per
+ * microsecond: with one per iteration the trace kernel took three times as long), and the blocks of a wave's paths -- the
+ * samples of one pixel, mostly -- stay together in memory, which the shade kernel's reads of a pixel's samples want. */
+#define POOL_CHUNK 256u
+struct WavePool
+{
+    uint32_t base, left; /* wave-uniform: first block of the current chunk not handed out yet, blocks left in it */
+    uint32_t taken;      /* per lane: blocks this lane's paths have opened (statistics; spares held at the end are not in it) */
+};
+
+/* Blocks for the lanes that `need` one. Must be called by the whole wave. Returns the lane's block, or ~0u when it needed one
+ * and the pool is exhausted (the caller raises tp.overflow). */
+__device__ __forceinline__ uint32_t pool_alloc(const TraceParams &tp, WavePool &wp, bool need, uint32_t lane)
+{
+    const unsigned long long m = __ballot(need);
+    if (m == 0ull) return ~0u;
+    const uint32_t n = (uint32_t)__popcll(m);
+    if (n > wp.left)
+    {
+        /* a new chunk (what is left of the old one, fewer than 64 blocks, stays unused) */
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(tp.pool_cursor, (unsigned long long)POOL_CHUNK);
+        base = __shfl(base, 0);
+        if (base + POOL_CHUNK > (unsigned long long)tp.pool_blocks)
+        {
+            wp.left = 0;
+            return ~0u;
+        }
+        wp.base = (uint32_t)base;
+        wp.left = POOL_CHUNK;
+    }
+    const uint32_t id = wp.base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    wp.base += n;
+    wp.left -= n;
+    return need ? id : ~0u;
+}
+
+/* Lanes keep one SPARE block, taken at the top of a loop iteration -- where little else is live -- whenever the path could
+ * start a new block at the vertex this iteration may reach (vertex number a multiple of four); a spare that is not used stays
+ * with the lane for its next path. Whole wave. Returns false for a lane whose path cannot go on (pool exhausted). */
+__device__ __forceinline__ bool path_spare_block(const TraceParams &tp, WavePool &wp, bool alive, uint32_t shaded, uint32_t &spare, uint32_t &spare_tbl,
+                                                 uint32_t lane)
+{
+    const bool want = alive && (shaded & (REC_BLOCK_VERTICES - 1u)) == 0u && spare == ~0u;
+    const bool want_tbl = alive && shaded == REC_HEADER_BLOCKS * REC_BLOCK_VERTICES && spare_tbl == ~0u;
+    const uint32_t id = pool_alloc(tp, wp, want, lane);
+    const uint32_t tid = pool_alloc(tp, wp, want_tbl, lane);
+    if (want) spare = id;
+    if (want_tbl) spare_tbl = tid;
+    if ((want && id == ~0u) || (want_tbl && tid == ~0u))
+    {
+        atomicExch(tp.overflow, 1u);
+        return false;
+    }
+    return true;
+}
+/* the path starts vertex number `shaded`: when that opens a block, the spare becomes it and is noted in the header (or the table) */
+__device__ __forceinline__ void path_open_vertex(const TraceParams &tp, WavePool &wp, uint64_t *__restrict__ records, uint32_t shaded, uint64_t *hdr,
+                                                 uint32_t &blk, uint32_t &tbl, uint32_t &spare, uint32_t &spare_tbl)
+{
+    if ((shaded & (REC_BLOCK_VERTICES - 1u)) != 0u) return;
+    const uint32_t b = shaded >> REC_BLOCK_SHIFT;
+    blk = spare;
+    spare = ~0u;
+    wp.taken += 1;
+    uint32_t *h32 = (uint32_t *)hdr;
+    if (b < REC_HEADER_BLOCKS) h32[4 + b] = blk; /* low / high half of w2, low half of w3 */
+    else
+    {
+        if (b == REC_HEADER_BLOCKS)
+        {
+            tbl = spare_tbl;
+            spare_tbl = ~0u;
+            h32[7] = tbl;
+            wp.taken += 1;
+        }
+        ((uint32_t *)(records + (uint64_t)tbl * tp.block_words))[b - REC_HEADER_BLOCKS] = blk;
+    }
+}
 
 struct EvalCoef
 {
@@ -160,7 +257,7 @@ struct EvalCoef
     uint32_t flags;
 };
 
-/* counters: [0] paths [1] closest-hit scans [2] shaded vertices [3] shadow scans [4] rng draws */
+/* counters: [0] paths [1] closest-hit scans [2] shaded vertices [3] shadow scans [4] rng draws [5] record blocks taken */
 #define DRT_NUM_COUNTERS 8
 
 /* ---------------------------------------------------------------------------------------------- */
@@ -735,7 +832,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
     uint32_t vis0_mask = 0;    /* bit v: light 0 is visible from shaded vertex v (< 8); header bits 24-31 */
     uint32_t plastic_mask = 0; /* bit v: shaded vertex v (< 16) has the two-lobe plastic list; header bits 48-63, read by the shade kernel's tail pass */
     V3 ro = v3(0, 0, 0), rd = v3(0, 0, 0);
-    uint64_t *rec = nullptr, *hdr = nullptr;
+    uint64_t *hdr = nullptr;
+    uint32_t blk = 0, tbl = 0;              /* the pool block of the current four vertices; the path's table block (deep paths) */
+    uint32_t spare = ~0u, spare_tbl = ~0u; /* a block (and, for deep paths, a table block) held ready: see path_spare_block */
+    WavePool wp = {0u, 0u, 0u};
+    if (*tp.overflow) return; /* an earlier launch ran out of record blocks: the host renders from there again */
 
     for (;;)
     {
@@ -815,7 +916,6 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
                 plastic_mask = 0;
                 vis0_mask = 0;
                 uint64_t slot = q * (uint64_t)tp.batch + s_local;
-                rec = records + slot * (uint64_t)tp.path_words;
                 hdr = headers + slot * REC_HEADER_WORDS;
                 /* vignette: dot(ray_direction, forward) of the PRIMARY ray, src/daily_ray_trace.c:614 */
                 hdr[1] = (uint64_t)__double_as_longlong(v_dot(rd, cam.forward) * 1.0);
@@ -829,6 +929,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
         }
         if (!__any(alive)) break;
 
+        /* a spare record block for the lanes whose path may open one at this iteration's vertex (the whole wave takes part) */
+        if (!path_spare_block(tp, wp, alive, shaded, spare, spare_tbl, lane))
+        {
+            hdr[0] = (uint64_t)HDR_TERM_NOT_DONE << 16;
+            alive = false;
+        }
         if (alive)
         {
             /* ---- one iteration of cast_ray's loop, src/daily_ray_trace.c:446-474 ---- */
@@ -848,7 +954,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
             }
             else
             {
-                uint64_t *vrec = rec + (uint64_t)shaded * tp.vertex_words;
+                path_open_vertex(tp, wp, records, shaded, hdr, blk, tbl, spare, spare_tbl);
+                uint64_t *vrec = records + (uint64_t)blk * tp.block_words + (uint64_t)(shaded & (REC_BLOCK_VERTICES - 1u)) * tp.vertex_words;
                 /* direct_light_contribution, :272-332 -- light samples are drawn before the shadow test */
                 n_shaded += 1;
                 for (uint32_t l = 0; l < sv.n_lights; l += 1)
@@ -928,8 +1035,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
     }
 
     /* statistics: wave reduction, one atomic per wave and counter */
-    uint64_t vals[5] = {n_paths, n_scans, n_shaded, n_shadow, n_draws};
-    for (int k = 0; k < 5; k += 1)
+    uint64_t vals[6] = {n_paths, n_scans, n_shaded, n_shadow, n_draws, wp.taken};
+    for (int k = 0; k < 6; k += 1)
     {
         uint64_t v = vals[k];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -950,8 +1057,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
 struct ShadeParams
 {
     uint64_t n_pix;
-    uint32_t n_samples, first_sample, vertex_words, path_words;
+    uint32_t n_samples, first_sample, vertex_words, block_words; /* a vertex record and a pool block (four vertices) in 8-byte words */
     uint32_t n_lights, batch;
+    const uint32_t *overflow; /* the trace launch ran out of record blocks: nothing here is touched */
+    uint32_t vertex_shift, pad3; /* log2(vertex_words) */
     uint32_t tail_first, tail_count; /* wavelengths [tail_first, tail_first + tail_count) go through the packed tail pass (0: none) */
     uint32_t chunk, sub_pixels;      /* pixels per group (= tail packing size when there is a tail); pixels per main-pass work item */
     uint32_t light0_em_spd, pad2;         /* emission SPD row of light 0 (what every light block of light 0 says) */
@@ -969,6 +1078,18 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l)
     uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
     uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l);
     return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+/* where vertex v of a path lives, from the header's block words (see the record layout above) */
+__device__ __forceinline__ const uint64_t *path_vertex(const uint64_t *__restrict__ pool, uint32_t block_words, uint32_t vw, uint64_t h2, uint64_t h3, uint32_t v)
+{
+    const uint32_t b = v >> REC_BLOCK_SHIFT;
+    uint32_t id;
+    if (b == 0) id = (uint32_t)h2;
+    else if (b == 1) id = (uint32_t)(h2 >> 32);
+    else if (b == 2) id = (uint32_t)h3;
+    else id = ((const uint32_t *)(pool + (uint64_t)(uint32_t)(h3 >> 32) * block_words))[b - REC_HEADER_BLOCKS];
+    return pool + (uint64_t)id * block_words + (uint64_t)(v & (REC_BLOCK_VERTICES - 1u)) * vw;
 }
 
 /* value of SPD row `idx` at wavelength `lam` */
@@ -1104,16 +1225,17 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
     uint32_t s = act ? 0u : sp.n_samples; /* lanes without a pixel are done from the start */
     uint32_t v = 0, n_shaded = 0, term = 0, term_spd = 0, plastic_mask = 0;
     double vignette = 0.0, throughput = 1.0, dst = 0.0;
-    const uint64_t *rp = records;
+    uint64_t ph2 = 0, ph3 = 0; /* the path's block words */
     auto open_sample = [&]() {
         const uint64_t slot = pix_l * sp.batch + s;
         const uint64_t h0 = headers[slot * REC_HEADER_WORDS], h1 = headers[slot * REC_HEADER_WORDS + 1];
+        ph2 = headers[slot * REC_HEADER_WORDS + 2];
+        ph3 = headers[slot * REC_HEADER_WORDS + 3];
         n_shaded = (uint32_t)(h0 & 0xFFFFu);
         term = (uint32_t)(h0 >> 16) & 0xFFu;
         term_spd = (uint32_t)(h0 >> 32) & 0xFFFFu;
         plastic_mask = (uint32_t)(h0 >> 48);
         vignette = word_as_double(h1);
-        rp = records + slot * (uint64_t)sp.path_words;
         v = 0;
         throughput = 1.0;
         dst = 0.0;
@@ -1130,7 +1252,7 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
             if (is_plastic)
             {
                 /* bdsf() over {bp_diffuse_bdsf, bp_glossy_bdsf}, straight-line (as in the main pass) */
-                const uint64_t *vrec = rp + (uint64_t)v * vw;
+                const uint64_t *vrec = path_vertex(records, sp.block_words, vw, ph2, ph3, v);
                 const uint64_t w1 = vrec[1];
                 const double dir_pdf = word_as_double(vrec[4]);
                 const double s_a_in = word_as_double(vrec[5]), s_spec = word_as_double(vrec[6]);
@@ -1162,7 +1284,7 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
             if (is_general)
             {
                 /* any BDSF list (also plastic vertices beyond the header's 16 flags) */
-                const uint64_t *vrec = rp + (uint64_t)v * vw;
+                const uint64_t *vrec = path_vertex(records, sp.block_words, vw, ph2, ph3, v);
                 const uint64_t list = vrec[0], w1 = vrec[1], w2 = vrec[2];
                 const double on_dot = word_as_double(vrec[3]), dir_pdf = word_as_double(vrec[4]);
                 const double s_a_in = word_as_double(vrec[5]), s_spec = word_as_double(vrec[6]);
@@ -1262,6 +1384,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
 {
     extern __shared__ double lds[];
     const uint32_t S = sc.S;
+    if (*sp.overflow) return; /* the records of this launch are incomplete: leave the film as it is (see the record layout) */
     if (SPDS_IN_LDS)
     {
         /* the SPD block [n_spd][S] is contiguous: coalesced copy */
@@ -1276,7 +1399,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
 #endif
     const uint32_t vw = sp.vertex_words;                 /* power of two >= 16 */
     const uint32_t vpr = vw <= 64 ? 64u / vw : 0u;       /* vertices per 64-word register (0: records wider than a register) */
-    const uint32_t n_fast = vpr * SHADE_PREFETCH_REGS;   /* vertices covered by the prefetch registers */
+    const uint32_t n_fast_regs = vpr * SHADE_PREFETCH_REGS;
+    const uint32_t n_fast = n_fast_regs < 2u * REC_BLOCK_VERTICES ? n_fast_regs : 2u * REC_BLOCK_VERTICES; /* vertices covered by the prefetch registers (blocks 0 and 1) */
 
     uint32_t lam_c[NSETS];
 #pragma unroll
@@ -1360,14 +1484,30 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
       for (uint32_t s0 = 0; s0 < sp.n_samples; s0 += 64u)
       {
         const uint32_t n_win = (sp.n_samples - s0 < 64u) ? sp.n_samples - s0 : 64u;
-        uint64_t h0 = 0, h1 = 0;
+        uint64_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
         if (lane < n_win)
         {
             const uint64_t *h = headers + (pix * sp.batch + s0 + lane) * REC_HEADER_WORDS;
             h0 = h[0];
             h1 = h[1];
+            h2 = h[2];
+            h3 = h[3];
         }
-        const uint64_t *rbase = records + (pix * (uint64_t)sp.batch + s0) * sp.path_words;
+        /* The first vertices of a path as the prefetch registers see them: register k, lane l holds word 64 k + l of the path's
+         * vertices laid end to end. A block is four vertices, 64 words or more, so a register never straddles blocks: one block
+         * number per register, from the header (scalar), and consecutive lanes read consecutive words. Only the header's own
+         * blocks are prefetched; deeper vertices are fetched when they are replayed. */
+        auto prefetch = [&](uint32_t sa, uint32_t nw, uint64_t *dst) {
+            const uint64_t b2 = readlane64(h2, sa);
+#pragma unroll
+            for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1)
+            {
+                const uint32_t b = (64u * k) >> (sp.vertex_shift + REC_BLOCK_SHIFT); /* 0 or 1: SHADE_PREFETCH_REGS <= 2 */
+                const uint32_t id = b == 0 ? (uint32_t)b2 : (uint32_t)(b2 >> 32);
+                const uint64_t *base = records + (uint64_t)id * sp.block_words + (64u * k - (b << (sp.vertex_shift + REC_BLOCK_SHIFT)));
+                dst[k] = (64u * k + lane < nw) ? base[lane] : 0;
+            }
+        };
         /* ring of prefetched records: ring[0] = the sample being replayed, ring[d] = d samples ahead. Memory
          * latency (~2 us) is several samples of replay, so the loads run SHADE_PREFETCH_DEPTH samples ahead. */
         uint64_t ring[SHADE_PREFETCH_DEPTH + 1][SHADE_PREFETCH_REGS];
@@ -1375,9 +1515,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
         for (int d = 0; d < SHADE_PREFETCH_DEPTH; d += 1)
         {
             const uint32_t nw = ((uint32_t)d < n_win) ? (uint32_t)(readlane64(h0, d) & 0xFFFFu) * vw : 0u;
-            const uint64_t *p = rbase + (uint64_t)d * sp.path_words;
-#pragma unroll
-            for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) ring[d + 1][k] = (64u * k + lane < nw) ? p[64u * k + lane] : 0;
+            prefetch((uint32_t)d < n_win ? (uint32_t)d : 0u, nw, ring[d + 1]);
         }
         for (uint32_t s = 0; s < n_win; s += 1)
         {
@@ -1388,7 +1526,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
             const uint32_t term_spd = (uint32_t)(hs >> 32) & 0xFFFFu;
             const uint32_t plastic_mask = (uint32_t)(hs >> 48); /* bit v: vertex v has the two-lobe plastic list */
             const uint32_t vis0_mask = (uint32_t)(hs >> 24) & 0xFFu; /* bit v (< 8): light 0 visible from vertex v */
-            const uint64_t *p_s = rbase + (uint64_t)s * sp.path_words;
             /* rotate the ring, then start the load for the sample SHADE_PREFETCH_DEPTH ahead */
 #pragma unroll
             for (int d = 0; d < SHADE_PREFETCH_DEPTH; d += 1)
@@ -1397,9 +1534,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
             {
                 const uint32_t sa = s + SHADE_PREFETCH_DEPTH;
                 const uint32_t nw = (sa < n_win) ? (uint32_t)(readlane64(h0, sa) & 0xFFFFu) * vw : 0u;
-                const uint64_t *p = rbase + (uint64_t)sa * sp.path_words;
-#pragma unroll
-                for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) ring[SHADE_PREFETCH_DEPTH][k] = (64u * k + lane < nw) ? p[64u * k + lane] : 0;
+                prefetch(sa < n_win ? sa : 0u, nw, ring[SHADE_PREFETCH_DEPTH]);
             }
             const uint64_t *cur = ring[0];
 #if DRT_SHADE_LDS_WORDS
@@ -1442,7 +1577,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
                 {
                     /* deep path or a record wider than a register: fetch the first 64 words of the vertex now */
                     lane0 = 0;
-                    src = (lane < vw) ? p_s[(uint64_t)v * vw + lane] : 0;
+                    src = (lane < vw) ? path_vertex(records, sp.block_words, vw, readlane64(h2, s), readlane64(h3, s), v)[lane] : 0;
                 }
                 const double *table = SPDS_IN_LDS ? (const double *)lds : sc.spds;
                 double contribution[NSETS];
@@ -1499,7 +1634,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
                             }
                             else
                             {
-                                const uint64_t *lp = p_s + (uint64_t)v * vw + off;
+                                const uint64_t *lp = path_vertex(records, sp.block_words, vw, readlane64(h2, s), readlane64(h3, s), v) + off;
 #pragma unroll
                                 for (int k = 0; k < 4; k += 1) lw[k] = readlane64(lp[k], 0);
                             }
@@ -1581,7 +1716,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_sha
                     else
                     {
                         /* light block beyond the register: uniform loads straight from the record */
-                        const uint64_t *lp = p_s + (uint64_t)v * vw + off;
+                        const uint64_t *lp = path_vertex(records, sp.block_words, vw, readlane64(h2, s), readlane64(h3, s), v) + off;
 #pragma unroll
                         for (int k = 0; k < REC_LIGHT_WORDS; k += 1) lw[k] = readlane64(lp[k], 0);
                     }

@@ -58,11 +58,19 @@ struct drt_context
     uint32_t  light0_em_spd = 0;      /* emission SPD row of the first light (0 when there is none) */
     double   *d_tail_stage = nullptr; /* [n_pix * batch][tail_count]: per-sample results of the shade kernel's tail pass */
     uint32_t  batch_spp = 1;
-    uint32_t  vertex_words = 0, path_words = 0;
+    uint32_t  vertex_words = 0, vertex_shift = 0, block_words = 0; /* a vertex record, its log2, a pool block (four vertices), in 8-byte words */
+    uint64_t  pool_blocks = 0;          /* blocks in d_records */
+    uint32_t  worst_blocks_per_path = 0; /* what a path of max_depth vertices takes (table block included) */
+    double    est_blocks_per_path = 0.0; /* measured on a sample of the tile when the context is created */
+    struct Batch { uint32_t first_sample, n_samples; uint64_t seq; };
+    std::vector<Batch> inflight;         /* kernel pairs enqueued since the last synchronisation (redone if the pool ran out) */
+    uint64_t  next_seq = 1;
+    uint64_t  redone_batches = 0, pool_peak = 0;
     int32_t  *d_hits = nullptr;
     uint64_t  hits_capacity = 0; /* in paths */
     uint32_t  hits_samples = 0;
-    unsigned long long *d_counters = nullptr; /* DRT_NUM_COUNTERS stats, then per kernel pair: trace queue, shade queue, bounce queue length, spare */
+    unsigned long long *d_counters = nullptr; /* DRT_NUM_COUNTERS stats; per kernel pair: trace queue, shade queue, bounce queue length, spare, pool cursor;
+                                                 then overflow flag, sequence number of the last complete kernel pair, peak of the pool cursor */
     PrimaryHit *d_primary = nullptr;          /* BVH pipeline: closest hit of every path's camera ray (drt_bvh_kernels.h) */
     uint64_t   *d_queue = nullptr;            /* BVH pipeline: ids of the paths that go on after their first hit */
     bool        bvh_pipeline = false;
@@ -634,6 +642,21 @@ static size_t pixels_bytes(const drt_context *ctx)
     return (size_t)ctx->n_pix * (ctx->xyz_mode ? (size_t)XYZ_FILM_WORDS : (size_t)ctx->dsc.S + 1) * 8;
 }
 
+static int enqueue_trace(drt_context *ctx, uint32_t first_sample, uint32_t n, uint32_t hits_sample_offset);
+
+/* waves of the trace-stage kernel that takes record blocks, for a launch of n_paths */
+static uint64_t trace_waves(const drt_context *ctx, uint64_t n_paths)
+{
+    const uint64_t cap = (uint64_t)(ctx->bvh_pipeline ? ctx->bounce_grid_cap : ctx->trace_grid_cap);
+    return std::min<uint64_t>(cap, (n_paths + TRACE_BLOCK - 1) / TRACE_BLOCK) * (TRACE_BLOCK / 64);
+}
+/* blocks that are enough for ANY launch of n_paths: every path max_depth vertices; fewer than 64 blocks of every POOL_CHUNK
+ * stay unused when a wave moves on to a new chunk, every wave ends on a part-used one, and its lanes on a spare (or two) each */
+static uint64_t blocks_worst_case(const drt_context *ctx, uint64_t n_paths)
+{
+    return (uint64_t)((double)n_paths * ctx->worst_blocks_per_path * (1.0 + 64.0 / POOL_CHUNK)) + trace_waves(ctx, n_paths) * (POOL_CHUNK + 2 * 64) + 1;
+}
+
 static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camera *camera, const drt_params *params)
 {
     if (!scene || !camera || !params) return fail(-1, "null argument");
@@ -670,52 +693,23 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
      * vertex never straddles the shade kernel's 64-word prefetch registers */
     ctx->vertex_words = 16;
     while (ctx->vertex_words < REC_VERTEX_WORDS + REC_LIGHT_WORDS * ctx->dsc.n_lights) ctx->vertex_words *= 2;
-    ctx->path_words = ctx->vertex_words * params->max_depth;
+    ctx->vertex_shift = 0;
+    while ((1u << ctx->vertex_shift) < ctx->vertex_words) ctx->vertex_shift += 1;
+    ctx->block_words = REC_BLOCK_VERTICES * ctx->vertex_words;
+    /* a path of max_depth vertices: a block per four, plus the table block once the header's three are used up */
+    const uint32_t deepest = (params->max_depth + REC_BLOCK_VERTICES - 1) / REC_BLOCK_VERTICES;
+    ctx->worst_blocks_per_path = deepest + (deepest > REC_HEADER_BLOCKS ? 1u : 0u);
+    if (deepest > REC_HEADER_BLOCKS + 2 * ctx->block_words)
+        return fail(-2, "max_depth %u: a path's table block holds %u blocks beyond the header's %d", params->max_depth, 2 * ctx->block_words, REC_HEADER_BLOCKS);
     if (ctx->dsc.n_spd >= 0xFFFFu) return fail(-2, "too many SPDs for the 16-bit record indices");
     if (S > 64 * SHADE_MAX_SETS) return fail(-2, "more than %d wavelengths", 64 * SHADE_MAX_SETS);
-
-    /* batch (samples per kernel pair): large launches are the efficient ones (their last round is amortised: DESIGN.md,
-     * work queues), but the record buffer grows with them and device memory a process touches for the first time is
-     * cleared by the driver -- 10-40 ms per GB, seconds for the 68 GB that suit a long-lived context. So the default
-     * follows the job the caller announces in params->spp: about 32 kernel pairs per job, at least 1 GB of records, at
-     * most 64 M paths per launch. Callers that keep a context across many frames pass batch_spp themselves. */
-    uint32_t batch = params->batch_spp;
-    if (batch == 0)
-    {
-        const uint64_t npx = std::max<uint64_t>(ctx->n_pix, 1);
-        const uint64_t path_bytes = (uint64_t)ctx->path_words * 8;
-        uint64_t by_job = (std::max<uint32_t>(params->spp, 1) + 31) / 32;
-        uint64_t by_floor = (1ull << 30) / (path_bytes * npx);
-        uint64_t cap = std::max<uint64_t>(1, std::min<uint64_t>(DRT_DEFAULT_MAX_BATCH, (64ull << 20) / npx));
-        batch = (uint32_t)std::max<uint64_t>(1, std::min(std::max(by_job, by_floor), cap));
-        if (params->spp) batch = std::min(batch, params->spp);
-    }
-    batch = std::min<uint32_t>(batch, 4096);
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    size_t film_bytes = ctx->xyz_mode ? (size_t)ctx->n_pix * XYZ_FILM_WORDS * 8 : (size_t)ctx->n_pix * (3 * (size_t)S + 1) * 8;
-    /* per path slot: the vertex records, the header, and the tail pass's staged results (when S leaves a tail) */
     {
         uint32_t sets = 0, tf = 0, tc = 0;
         shade_sets(S, &sets, &tf, &tc);
         ctx->tail_count = tc;
     }
-    const size_t slot_bytes = (size_t)ctx->path_words * 8 + REC_HEADER_WORDS * 8 + (size_t)ctx->tail_count * 8 +
-                              ((ctx->use_bvh && ctx->dsc.bvh_nodes) ? sizeof(PrimaryHit) + sizeof(uint64_t) : 0);
-    while (batch > 1 && (size_t)ctx->n_pix * batch * slot_bytes + film_bytes > free_b / 2) batch /= 2;
-    ctx->batch_spp = batch;
-    size_t rec_bytes = (size_t)ctx->n_pix * batch * ctx->path_words * 8;
-    if ((size_t)ctx->n_pix * batch * slot_bytes + film_bytes > free_b)
-        return fail(-3, "not enough device memory: need %zu bytes", (size_t)ctx->n_pix * batch * slot_bytes + film_bytes);
-    HIP_TRY(hipMalloc((void **)&ctx->d_records, rec_bytes));
-    HIP_TRY(hipMalloc((void **)&ctx->d_headers, (size_t)ctx->n_pix * batch * REC_HEADER_WORDS * 8));
     /* scenes behind the hierarchy: camera rays walk it a wave at a time, the rest of each path runs from a queue (drt_bvh_kernels.h) */
-    ctx->bvh_pipeline = ctx->use_bvh && ctx->dsc.bvh_nodes && !getenv("DRT_BVH_ONE_KERNEL");
-    if (ctx->bvh_pipeline)
-    {
-        HIP_TRY(hipMalloc((void **)&ctx->d_primary, (size_t)ctx->n_pix * batch * sizeof(PrimaryHit)));
-        HIP_TRY(hipMalloc((void **)&ctx->d_queue, (size_t)ctx->n_pix * batch * sizeof(uint64_t)));
-    }
+    ctx->bvh_pipeline = !ctx->scene_in_lds;
 
     HIP_TRY(hipMalloc((void **)&ctx->d_pixels, pixels_bytes(ctx)));
     if (!ctx->xyz_mode)
@@ -727,8 +721,8 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     HIP_TRY(hipMemsetAsync(ctx->d_pixels, 0, pixels_bytes(ctx), ctx->stream));
     if (ctx->d_avgs) HIP_TRY(hipMemsetAsync(ctx->d_avgs, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
     if (ctx->d_vars) HIP_TRY(hipMemsetAsync(ctx->d_vars, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
-    HIP_TRY(hipMalloc((void **)&ctx->d_counters, (DRT_NUM_COUNTERS + 4) * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 4) * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMalloc((void **)&ctx->d_counters, (DRT_NUM_COUNTERS + 8) * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 8) * sizeof(unsigned long long), ctx->stream));
 
     /* persistent trace grid: as many workgroups as the chip keeps resident */
     hipDeviceProp_t prop;
@@ -736,8 +730,6 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     int per_cu = 0;
     if (ctx->scene_in_lds)
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, drt_trace_kernel<true>, TRACE_BLOCK, ctx->trace_lds));
-    else
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, drt_trace_kernel<false>, TRACE_BLOCK, 0));
     if (per_cu < 1) per_cu = 1;
     if (const char *e = getenv("DRT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e)); /* tuning knob */
     ctx->trace_grid_cap = prop.multiProcessorCount * per_cu;
@@ -755,7 +747,6 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     if (DRT_SHADE_LDS_WORDS) ctx->shade_lds += (size_t)SHADE_WAVES * 2 * 64 * SHADE_PREFETCH_REGS * 8; /* two record slots per wave */
     int s_per_cu = 0;
     shade_sets(S, &ctx->shade_sets, &ctx->tail_first, &ctx->tail_count);
-    if (ctx->tail_count) HIP_TRY(hipMalloc((void **)&ctx->d_tail_stage, (size_t)ctx->n_pix * ctx->batch_spp * ctx->tail_count * 8));
     switch (ctx->shade_sets)
     {
         case 1: rc = shade_occupancy<1>(ctx, &s_per_cu); break;
@@ -779,9 +770,103 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     if (const char *e = getenv("DRT_TRACE_CHUNK")) ctx->trace_chunk_override = (uint32_t)std::min(1 << 20, std::max(64, atoi(e) / 64 * 64));
     if (const char *e = getenv("DRT_TAIL_PERIOD")) ctx->tail_period_override = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("DRT_SHADE_SUBS")) ctx->shade_subs_override = (uint32_t)std::max(0, atoi(e));
+    /*
+     * The record pool and the launch size. A launch of N paths needs about N * b blocks, b = blocks per path on THIS tile of
+     * THIS scene (0.9 on the Cornell frame, where a worst-case path would take 4): b is measured here, once, on a sample of the
+     * tile (every k-th row, one sample per pixel, traced into a small pool sized for the worst case), and the pool gets 1.2 b
+     * per path, a quarter more for what the waves' chunks leave unused, and a margin for small launches -- so 64 M paths take
+     * 28 GB instead of 68. If a launch runs out after all, its
+     * shade kernel and everything queued behind it do nothing and the host renders those samples again in launches sized for the
+     * worst case (redo_batches): slower, never wrong. Launch size: large launches are the efficient ones (their last round is
+     * amortised: DESIGN.md, work queues); the default follows the job announced in params->spp -- about 32 kernel pairs, at least
+     * 6 GB of records, at most 64 M paths per launch -- because device memory a process touches for the first time is cleared by
+     * the driver (10-40 ms per GB). Callers that keep a context across many frames pass batch_spp themselves.
+     */
+    const size_t block_bytes = (size_t)ctx->block_words * 8;
+    const uint64_t npx = std::max<uint64_t>(ctx->n_pix, 1);
+    const size_t per_path_fixed = REC_HEADER_WORDS * 8 + (size_t)ctx->tail_count * 8 + (ctx->bvh_pipeline ? sizeof(PrimaryHit) + sizeof(uint64_t) : 0);
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    ctx->est_blocks_per_path = (double)ctx->worst_blocks_per_path;
+    if (npx * (uint64_t)ctx->worst_blocks_per_path * block_bytes > (256ull << 20) && !getenv("DRT_POOL_WORST_CASE"))
+    {
+        /* the sample: tile rows 0, k, 2k, ... with k such that it holds about 128 k paths */
+        const uint32_t k = (uint32_t)std::max<uint64_t>(1, npx / (128u << 10));
+        drt_params pp = ctx->params;
+        pp.tile_h = (ctx->params.tile_h + k - 1) / k;
+        pp.row_stride = ctx->params.row_stride * k;
+        const uint64_t n_sample = (uint64_t)pp.tile_w * pp.tile_h;
+        ctx->n_pix = n_sample;
+        ctx->pool_blocks = blocks_worst_case(ctx, n_sample);
+        ctx->n_pix = npx;
+        HIP_TRY(hipMalloc((void **)&ctx->d_records, ctx->pool_blocks * block_bytes));
+        HIP_TRY(hipMalloc((void **)&ctx->d_headers, n_sample * REC_HEADER_WORDS * 8));
+        if (ctx->bvh_pipeline)
+        {
+            HIP_TRY(hipMalloc((void **)&ctx->d_primary, n_sample * sizeof(PrimaryHit)));
+            HIP_TRY(hipMalloc((void **)&ctx->d_queue, n_sample * sizeof(uint64_t)));
+        }
+        const drt_params keep = ctx->params;
+        const uint64_t keep_pix = ctx->n_pix;
+        ctx->params = pp;
+        ctx->params.flags &= ~(uint32_t)DRT_FLAG_RECORD_HITS;
+        ctx->n_pix = n_sample;
+        ctx->batch_spp = 1;
+        rc = enqueue_trace(ctx, keep.first_sample, 1, 0);
+        ctx->params = keep;
+        ctx->n_pix = keep_pix;
+        if (rc) return rc;
+        unsigned long long used = 0; /* blocks handed to paths (the cursor also counts the waves' part-used chunks) */
+        HIP_TRY(hipMemcpyAsync(&used, ctx->d_counters + 5, sizeof(used), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->est_blocks_per_path = (double)used / (double)n_sample;
+        (void)hipFree(ctx->d_records); ctx->d_records = nullptr;
+        (void)hipFree(ctx->d_headers); ctx->d_headers = nullptr;
+        (void)hipFree(ctx->d_primary); ctx->d_primary = nullptr;
+        (void)hipFree(ctx->d_queue); ctx->d_queue = nullptr;
+        HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 8) * sizeof(unsigned long long), ctx->stream)); /* the sample does not count */
+        ctx->ev_used = 0;
+    }
+    /* blocks a launch of n paths is given: 1.3 x the expectation, 8 sigma of a sum of n on top (a path's block count has a
+     * standard deviation below 2), never less than one sample per pixel in the worst case (what redo_batches launches) */
+    auto blocks_for = [&](uint64_t n_paths) -> uint64_t {
+        const double want = 1.2 * ctx->est_blocks_per_path * (double)n_paths + 16.0 * std::sqrt((double)n_paths) + 4096.0;
+        const uint64_t expect = (uint64_t)(want * (1.0 + 64.0 / POOL_CHUNK)) + trace_waves(ctx, n_paths) * (POOL_CHUNK + 2 * 64) + 1; /* + the lanes' spares */
+        return std::max<uint64_t>(std::min<uint64_t>(expect, blocks_worst_case(ctx, n_paths)), blocks_worst_case(ctx, npx));
+    };
+    uint32_t batch = params->batch_spp;
+    if (batch == 0)
+    {
+        const double path_bytes = 1.2 * (1.0 + 64.0 / POOL_CHUNK) * ctx->est_blocks_per_path * (double)block_bytes + (double)per_path_fixed;
+        uint64_t by_job = (std::max<uint32_t>(params->spp, 1) + 31) / 32;
+        uint64_t by_floor = (uint64_t)((double)(6ull << 30) / (path_bytes * (double)npx));
+        uint64_t cap = std::max<uint64_t>(1, std::min<uint64_t>(DRT_DEFAULT_MAX_BATCH, (64ull << 20) / npx));
+        batch = (uint32_t)std::max<uint64_t>(1, std::min(std::max(by_job, by_floor), cap));
+        if (params->spp) batch = std::min(batch, params->spp);
+    }
+    batch = std::min<uint32_t>(batch, 4096);
+    const size_t film_bytes = ctx->xyz_mode ? (size_t)ctx->n_pix * XYZ_FILM_WORDS * 8 : (size_t)ctx->n_pix * (3 * (size_t)S + 1) * 8;
+    (void)film_bytes; /* allocated above: free_b already excludes it */
+    auto bytes_for = [&](uint32_t b) -> size_t { return blocks_for(npx * b) * block_bytes + (size_t)npx * b * per_path_fixed; };
+    while (batch > 1 && bytes_for(batch) > free_b / 2) batch /= 2;
+    if (bytes_for(batch) > free_b) return fail(-3, "not enough device memory: need %zu bytes", bytes_for(batch));
+    ctx->batch_spp = batch;
+    ctx->pool_blocks = blocks_for(npx * batch);
+    if (const char *e = getenv("DRT_POOL_BLOCKS")) /* test knob: a pool this small (never below one worst-case sample per pixel) */
+        ctx->pool_blocks = std::max<uint64_t>(blocks_worst_case(ctx, npx), std::min<uint64_t>(ctx->pool_blocks, strtoull(e, nullptr, 0)));
+    if (ctx->pool_blocks >= 0xFFFFFFF0ull) return fail(-3, "record pool of %llu blocks: block numbers are 32 bits", (unsigned long long)ctx->pool_blocks);
+    HIP_TRY(hipMalloc((void **)&ctx->d_records, ctx->pool_blocks * block_bytes));
+    HIP_TRY(hipMalloc((void **)&ctx->d_headers, (size_t)npx * batch * REC_HEADER_WORDS * 8));
+    if (ctx->bvh_pipeline)
+    {
+        HIP_TRY(hipMalloc((void **)&ctx->d_primary, (size_t)npx * batch * sizeof(PrimaryHit)));
+        HIP_TRY(hipMalloc((void **)&ctx->d_queue, (size_t)npx * batch * sizeof(uint64_t)));
+    }
+    if (ctx->tail_count) HIP_TRY(hipMalloc((void **)&ctx->d_tail_stage, (size_t)npx * batch * ctx->tail_count * 8));
     if (getenv("DRT_VERBOSE"))
-        fprintf(stderr, "drt: %d CUs, trace %d blocks/CU (lds %zu), shade %d blocks/CU (lds %zu), batch %u, path_words %u\n",
-                prop.multiProcessorCount, per_cu, ctx->trace_lds, s_per_cu, ctx->shade_lds, ctx->batch_spp, ctx->path_words);
+        fprintf(stderr, "drt: %d CUs, trace %d blocks/CU (lds %zu), shade %d blocks/CU (lds %zu), batch %u, %.3f blocks/path measured (worst %u), pool %.2f GB\n",
+                prop.multiProcessorCount, per_cu, ctx->trace_lds, s_per_cu, ctx->shade_lds, ctx->batch_spp, ctx->est_blocks_per_path,
+                ctx->worst_blocks_per_path, (double)(ctx->pool_blocks * block_bytes) / 1e9);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -854,6 +939,9 @@ extern "C" int drt_set_stream(drt_context *ctx, void *hip_stream)
     return 0;
 }
 
+extern "C" int drt_synchronize(drt_context *ctx);
+static int enqueue_trace(drt_context *ctx, uint32_t first_sample, uint32_t n, uint32_t hits_sample_offset);
+
 static int next_events(drt_context *ctx, hipEvent_t out[3])
 {
     while (ctx->ev.size() < ctx->ev_used + 3)
@@ -882,6 +970,176 @@ static int collect_timings(drt_context *ctx)
     return 0;
 }
 
+/* after a kernel pair: if the pool did not run out, this pair is the last complete one; the pool's high-water mark */
+__global__ void drt_mark_pair_kernel(unsigned long long *state, unsigned long long seq)
+{
+    /* state[0] pool cursor of this pair, [1] overflow flag, [2] last complete pair, [3] peak of the cursor */
+    if (*(const uint32_t *)(state + 1) == 0u) state[2] = seq;
+    if (state[0] > state[3]) state[3] = state[0];
+}
+
+/* The trace stage of one kernel pair over samples [first_sample, first_sample + n) of every tile pixel: work queues and the
+ * pool cursor reset, then drt_trace_kernel (scene in LDS) or drt_primary_kernel + drt_bounce_kernel (scene behind the hierarchy). */
+static int enqueue_trace(drt_context *ctx, uint32_t first_sample, uint32_t n, uint32_t hits_sample_offset)
+{
+    const drt_params &p = ctx->params;
+    TraceParams tp{};
+    tp.width = p.width; tp.height = p.height; tp.x0 = p.x0; tp.y0 = p.y0;
+    tp.tile_w = p.tile_w; tp.tile_h = p.tile_h; tp.row_stride = p.row_stride;
+    tp.first_sample = first_sample;
+    tp.n_samples = n;
+    tp.max_depth = p.max_depth;
+    tp.pixel_scheme = p.pixel_scheme;
+    tp.record_hits = (p.flags & DRT_FLAG_RECORD_HITS) ? 1u : 0u;
+    tp.seed = p.seed;
+    tp.n_pix = ctx->n_pix;
+    tp.n_paths = ctx->n_pix * n;
+    tp.vertex_words = ctx->vertex_words;
+    tp.block_words = ctx->block_words;
+    tp.hits_sample_offset = hits_sample_offset;
+    tp.batch = ctx->batch_spp;
+    tp.pool_blocks = (uint32_t)ctx->pool_blocks;
+    unsigned long long *work = ctx->d_counters + DRT_NUM_COUNTERS;
+    tp.pool_cursor = work + 4;
+    tp.overflow = (uint32_t *)(work + 5);
+    HIP_TRY(hipMemsetAsync(work, 0, 5 * sizeof(unsigned long long), ctx->stream)); /* trace + shade work queues, bounce queue length, spare, pool cursor */
+    uint64_t blocks_needed = (tp.n_paths + TRACE_BLOCK - 1) / TRACE_BLOCK;
+    const int grid_cap = ctx->bvh_pipeline ? ctx->bounce_grid_cap : ctx->trace_grid_cap;
+    uint32_t grid = (uint32_t)std::min<uint64_t>(blocks_needed, (uint64_t)grid_cap);
+    /* work-queue granularity: about 16 draws per wave, so that the last draws finish together; 64..1024 path ids */
+    {
+        uint64_t waves = (uint64_t)grid * (TRACE_BLOCK / 64);
+        uint64_t c = tp.n_paths / (waves * 16) / 64 * 64;
+        tp.chunk = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c, 64), ctx->bvh_pipeline ? 256 : 1024); /* queued paths all cost alike: small draws (config 5: 827 ms at 64-256, 855 at 1024) */
+        if (ctx->trace_chunk_override) tp.chunk = ctx->trace_chunk_override;
+    }
+    if (ctx->bvh_pipeline)
+    {
+        /* camera rays: a wave per 64 path ids; then the queued paths, one per lane */
+        const uint64_t packets = (tp.n_paths + 63) / 64;
+        const uint32_t pgrid = (uint32_t)std::min<uint64_t>((packets + PRIMARY_BLOCK / 64 - 1) / (PRIMARY_BLOCK / 64), (uint64_t)ctx->primary_grid_cap);
+        hipLaunchKernelGGL(drt_primary_kernel, dim3(pgrid), dim3(PRIMARY_BLOCK), 0, ctx->stream, ctx->dsc, ctx->dcam, tp, ctx->d_headers,
+                           ctx->d_hits, ctx->d_counters, ctx->d_primary, ctx->d_queue, work + 2);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(drt_bounce_kernel, dim3(grid), dim3(BOUNCE_BLOCK), 0, ctx->stream, ctx->dsc, ctx->dcam, tp, ctx->d_records,
+                           ctx->d_headers, ctx->d_hits, ctx->d_counters, work, ctx->d_primary, ctx->d_queue, work + 2);
+    }
+    else
+        hipLaunchKernelGGL(drt_trace_kernel<true>, dim3(grid), dim3(TRACE_BLOCK), ctx->trace_lds, ctx->stream, ctx->dsc,
+                           ctx->dcam, tp, ctx->d_records, ctx->d_headers, ctx->d_hits, ctx->d_counters, work);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* One kernel pair: trace, shade + film, and the mark that tells the host whether the pair was complete. */
+static int enqueue_pair(drt_context *ctx, uint32_t first_sample, uint32_t n, uint32_t hits_sample_offset)
+{
+    hipEvent_t ev[3];
+    int rc = next_events(ctx, ev);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ev[0], ctx->stream));
+    if ((rc = enqueue_trace(ctx, first_sample, n, hits_sample_offset))) return rc;
+    HIP_TRY(hipEventRecord(ev[1], ctx->stream));
+
+    unsigned long long *work = ctx->d_counters + DRT_NUM_COUNTERS;
+    ShadeParams sp{};
+    sp.n_pix = ctx->n_pix;
+    sp.n_samples = n;
+    sp.first_sample = first_sample;
+    sp.vertex_words = ctx->vertex_words;
+    sp.vertex_shift = ctx->vertex_shift;
+    sp.block_words = ctx->block_words;
+    sp.overflow = (const uint32_t *)(work + 5);
+    sp.n_lights = ctx->dsc.n_lights;
+    sp.batch = ctx->batch_spp;
+    sp.tail_first = ctx->tail_first;
+    sp.tail_count = ctx->tail_count;
+    sp.tail_stage = ctx->d_tail_stage;
+    sp.light0_em_spd = ctx->light0_em_spd;
+    sp.cmf_rw = ctx->cmf_rw; sp.cmf_x = ctx->cmf_x; sp.cmf_y = ctx->cmf_y; sp.cmf_z = ctx->cmf_z;
+    sp.chunk = ctx->tail_count ? 64u / ctx->tail_count : SHADE_PIXEL_CHUNK;
+    uint64_t groups = (ctx->n_pix + sp.chunk - 1) / sp.chunk;
+    const bool inline_tail = ctx->tail_count != 0;
+    /* work items: a group's main pass in pieces of sub_pixels pixels (+ its tail pass as an item of its own) when the
+     * groups alone are too few to keep the last round of the persistent waves short */
+    {
+        const uint64_t waves = (uint64_t)ctx->shade_grid_cap * SHADE_WAVES;
+        uint32_t subs = ctx->shade_subs_override;
+        if (subs == ~0u)
+        {
+            /* pixels per main-pass item: small enough for >= 64 items per wave (short last round), large enough for
+             * >= 256 paths per item (the queue is one atomic counter) */
+            uint64_t p_balance = ctx->n_pix / (waves * 64);
+            uint64_t p_atomic = (256 + n - 1) / n;
+            uint32_t P = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(std::max(p_balance, p_atomic), 1), sp.chunk);
+            subs = (sp.chunk + P - 1) / P;
+            if (subs == 1 && !inline_tail) subs = 0;
+        }
+        subs = std::min(subs, sp.chunk);
+        if (subs == 0 || (subs == 1 && !inline_tail) || groups * (uint64_t)(sp.chunk + 1) >= 0xFFFFFFFFull)
+        {
+            sp.sub_pixels = sp.chunk;
+            sp.items_per_group = 1;
+        }
+        else
+        {
+            sp.sub_pixels = (sp.chunk + subs - 1) / subs;
+            sp.items_per_group = (sp.chunk + sp.sub_pixels - 1) / sp.sub_pixels + (inline_tail ? 1 : 0);
+        }
+        if (groups * sp.items_per_group >= 0xFFFFFFFFull) return fail(-1, "tile too large for the shade work queue");
+        sp.n_items = (uint32_t)(groups * sp.items_per_group);
+        if (inline_tail && sp.items_per_group > 1)
+        {
+            uint32_t mains = sp.items_per_group - 1;
+            /* tail items (the longest ones) evenly through the queue when every wave gets many of them; when a wave gets
+             * only a few (small tiles), the last fifth of the queue is main-pass pieces only, so the launch ends on short items */
+            sp.tail_period_mains = (groups >= 8 * waves) ? mains : std::max<uint32_t>(1, mains * 4 / 5);
+            if (ctx->tail_period_override) sp.tail_period_mains = std::min(mains, ctx->tail_period_override);
+        }
+    }
+    uint32_t sgrid = (uint32_t)std::min<uint64_t>(((uint64_t)sp.n_items + SHADE_WAVES - 1) / SHADE_WAVES, (uint64_t)ctx->shade_grid_cap);
+    rc = launch_shade(ctx, sgrid, sp);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    const uint64_t seq = ctx->next_seq++;
+    hipLaunchKernelGGL(drt_mark_pair_kernel, dim3(1), dim3(1), 0, ctx->stream, work + 4, (unsigned long long)seq);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev[2], ctx->stream));
+    ctx->inflight.push_back({first_sample, n, seq});
+    return 0;
+}
+
+/* The pool ran out in some kernel pair: that pair's shade kernel and every later kernel did nothing. Render those samples again,
+ * in launches small enough for the worst case (every path max_depth vertices), synchronously. */
+static int redo_batches(drt_context *ctx, uint64_t last_good_seq)
+{
+    std::vector<drt_context::Batch> todo;
+    for (const auto &b : ctx->inflight) if (b.seq > last_good_seq) todo.push_back(b);
+    ctx->inflight.clear();
+    unsigned long long *work = ctx->d_counters + DRT_NUM_COUNTERS;
+    HIP_TRY(hipMemsetAsync(work + 5, 0, sizeof(unsigned long long), ctx->stream)); /* the overflow flag */
+    /* samples per launch that fit the pool whatever the paths do (one always does: the pool is never smaller, create_impl) */
+    uint32_t safe = 1;
+    while (safe < ctx->batch_spp && blocks_worst_case(ctx, ctx->n_pix * (uint64_t)(safe + 1)) <= ctx->pool_blocks) safe += 1;
+    for (const auto &b : todo)
+    {
+        ctx->redone_batches += 1;
+        for (uint32_t done = 0; done < b.n_samples; done += safe)
+        {
+            /* (hit logging, when on, is indexed by sample offset within the caller's drt_render call: the offsets of a redone
+             *  batch are not known here, and parity tests that log hits never run with an undersized pool) */
+            int rc = enqueue_pair(ctx, b.first_sample + done, std::min(safe, b.n_samples - done), done);
+            if (rc) return rc;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    unsigned long long st[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(st, work + 4, sizeof(st), hipMemcpyDeviceToHost));
+    if ((uint32_t)st[1] != 0u) return fail(-6, "record pool exhausted in a launch sized for the worst case (%llu blocks)", (unsigned long long)ctx->pool_blocks);
+    ctx->inflight.clear();
+    return 0;
+}
+
 extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_samples)
 {
     if (!ctx) return fail(-1, "null context");
@@ -904,123 +1162,13 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
     /* keep the number of pending timing events bounded */
     if (ctx->ev_used >= 3 * 256)
     {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        int rc = collect_timings(ctx);
+        int rc = drt_synchronize(ctx);
         if (rc) return rc;
     }
     for (uint32_t done = 0; done < num_samples; done += ctx->batch_spp)
     {
-        uint32_t n = std::min(ctx->batch_spp, num_samples - done);
-        TraceParams tp{};
-        tp.width = p.width; tp.height = p.height; tp.x0 = p.x0; tp.y0 = p.y0;
-        tp.tile_w = p.tile_w; tp.tile_h = p.tile_h; tp.row_stride = p.row_stride;
-        tp.first_sample = first_sample + done;
-        tp.n_samples = n;
-        tp.max_depth = p.max_depth;
-        tp.pixel_scheme = p.pixel_scheme;
-        tp.record_hits = (p.flags & DRT_FLAG_RECORD_HITS) ? 1u : 0u;
-        tp.seed = p.seed;
-        tp.n_pix = ctx->n_pix;
-        tp.n_paths = ctx->n_pix * n;
-        tp.vertex_words = ctx->vertex_words;
-        tp.path_words = ctx->path_words;
-        tp.hits_sample_offset = done;
-        tp.batch = ctx->batch_spp;
-
-        hipEvent_t ev[3];
-        int rc = next_events(ctx, ev);
+        int rc = enqueue_pair(ctx, first_sample + done, std::min(ctx->batch_spp, num_samples - done), done);
         if (rc) return rc;
-        unsigned long long *work = ctx->d_counters + DRT_NUM_COUNTERS;
-        HIP_TRY(hipMemsetAsync(work, 0, 4 * sizeof(unsigned long long), ctx->stream)); /* trace + shade work queues, bounce queue length */
-        uint64_t blocks_needed = (tp.n_paths + TRACE_BLOCK - 1) / TRACE_BLOCK;
-        const int grid_cap = ctx->bvh_pipeline ? ctx->bounce_grid_cap : ctx->trace_grid_cap;
-        uint32_t grid = (uint32_t)std::min<uint64_t>(blocks_needed, (uint64_t)grid_cap);
-        /* work-queue granularity: about 16 draws per wave, so that the last draws finish together; 64..1024 path ids */
-        {
-            uint64_t waves = (uint64_t)grid * (TRACE_BLOCK / 64);
-            uint64_t c = tp.n_paths / (waves * 16) / 64 * 64;
-            tp.chunk = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c, 64), ctx->bvh_pipeline ? 256 : 1024); /* queued paths all cost alike: small draws (config 5: 827 ms at 64-256, 855 at 1024) */
-            if (ctx->trace_chunk_override) tp.chunk = ctx->trace_chunk_override;
-        }
-        HIP_TRY(hipEventRecord(ev[0], ctx->stream));
-        if (ctx->bvh_pipeline)
-        {
-            /* camera rays: a wave per 64 path ids; then the queued paths, one per lane */
-            const uint64_t packets = (tp.n_paths + 63) / 64;
-            const uint32_t pgrid = (uint32_t)std::min<uint64_t>((packets + PRIMARY_BLOCK / 64 - 1) / (PRIMARY_BLOCK / 64), (uint64_t)ctx->primary_grid_cap);
-            hipLaunchKernelGGL(drt_primary_kernel, dim3(pgrid), dim3(PRIMARY_BLOCK), 0, ctx->stream, ctx->dsc, ctx->dcam, tp, ctx->d_headers,
-                               ctx->d_hits, ctx->d_counters, ctx->d_primary, ctx->d_queue, work + 2);
-            HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(drt_bounce_kernel, dim3(grid), dim3(BOUNCE_BLOCK), 0, ctx->stream, ctx->dsc, ctx->dcam, tp, ctx->d_records,
-                               ctx->d_headers, ctx->d_hits, ctx->d_counters, work, ctx->d_primary, ctx->d_queue, work + 2);
-        }
-        else if (ctx->scene_in_lds)
-            hipLaunchKernelGGL(drt_trace_kernel<true>, dim3(grid), dim3(TRACE_BLOCK), ctx->trace_lds, ctx->stream, ctx->dsc,
-                               ctx->dcam, tp, ctx->d_records, ctx->d_headers, ctx->d_hits, ctx->d_counters, work);
-        else
-            hipLaunchKernelGGL(drt_trace_kernel<false>, dim3(grid), dim3(TRACE_BLOCK), 0, ctx->stream, ctx->dsc, ctx->dcam, tp,
-                               ctx->d_records, ctx->d_headers, ctx->d_hits, ctx->d_counters, work);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(ev[1], ctx->stream));
-
-        ShadeParams sp{};
-        sp.n_pix = ctx->n_pix;
-        sp.n_samples = n;
-        sp.first_sample = first_sample + done;
-        sp.vertex_words = ctx->vertex_words;
-        sp.path_words = ctx->path_words;
-        sp.n_lights = ctx->dsc.n_lights;
-        sp.batch = ctx->batch_spp;
-        sp.tail_first = ctx->tail_first;
-        sp.tail_count = ctx->tail_count;
-        sp.tail_stage = ctx->d_tail_stage;
-        sp.light0_em_spd = ctx->light0_em_spd;
-        sp.cmf_rw = ctx->cmf_rw; sp.cmf_x = ctx->cmf_x; sp.cmf_y = ctx->cmf_y; sp.cmf_z = ctx->cmf_z;
-        sp.chunk = ctx->tail_count ? 64u / ctx->tail_count : SHADE_PIXEL_CHUNK;
-        uint64_t groups = (ctx->n_pix + sp.chunk - 1) / sp.chunk;
-        const bool inline_tail = ctx->tail_count != 0;
-        /* work items: a group's main pass in pieces of sub_pixels pixels (+ its tail pass as an item of its own) when the
-         * groups alone are too few to keep the last round of the persistent waves short */
-        {
-            const uint64_t waves = (uint64_t)ctx->shade_grid_cap * SHADE_WAVES;
-            uint32_t subs = ctx->shade_subs_override;
-            if (subs == ~0u)
-            {
-                /* pixels per main-pass item: small enough for >= 64 items per wave (short last round), large enough for
-                 * >= 256 paths per item (the queue is one atomic counter) */
-                uint64_t p_balance = ctx->n_pix / (waves * 64);
-                uint64_t p_atomic = (256 + n - 1) / n;
-                uint32_t P = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(std::max(p_balance, p_atomic), 1), sp.chunk);
-                subs = (sp.chunk + P - 1) / P;
-                if (subs == 1 && !inline_tail) subs = 0;
-            }
-            subs = std::min(subs, sp.chunk);
-            if (subs == 0 || (subs == 1 && !inline_tail) || groups * (uint64_t)(sp.chunk + 1) >= 0xFFFFFFFFull)
-            {
-                sp.sub_pixels = sp.chunk;
-                sp.items_per_group = 1;
-            }
-            else
-            {
-                sp.sub_pixels = (sp.chunk + subs - 1) / subs;
-                sp.items_per_group = (sp.chunk + sp.sub_pixels - 1) / sp.sub_pixels + (inline_tail ? 1 : 0);
-            }
-            if (groups * sp.items_per_group >= 0xFFFFFFFFull) return fail(-1, "tile too large for the shade work queue");
-            sp.n_items = (uint32_t)(groups * sp.items_per_group);
-            if (inline_tail && sp.items_per_group > 1)
-            {
-                uint32_t mains = sp.items_per_group - 1;
-                /* tail items (the longest ones) evenly through the queue when every wave gets many of them; when a wave gets
-                 * only a few (small tiles), the last fifth of the queue is main-pass pieces only, so the launch ends on short items */
-                sp.tail_period_mains = (groups >= 8 * waves) ? mains : std::max<uint32_t>(1, mains * 4 / 5);
-                if (ctx->tail_period_override) sp.tail_period_mains = std::min(mains, ctx->tail_period_override);
-            }
-        }
-        uint32_t sgrid = (uint32_t)std::min<uint64_t>(((uint64_t)sp.n_items + SHADE_WAVES - 1) / SHADE_WAVES, (uint64_t)ctx->shade_grid_cap);
-        rc = launch_shade(ctx, sgrid, sp);
-        if (rc) return rc;
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(ev[2], ctx->stream));
     }
     return 0;
 }
@@ -1030,7 +1178,21 @@ extern "C" int drt_synchronize(drt_context *ctx)
     if (!ctx) return fail(-1, "null context");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return collect_timings(ctx);
+    int rc = collect_timings(ctx);
+    if (rc) return rc;
+    if (!ctx->inflight.empty())
+    {
+        unsigned long long st[4] = {0, 0, 0, 0}; /* pool cursor, overflow flag, last complete pair, peak of the cursor */
+        HIP_TRY(hipMemcpy(st, ctx->d_counters + DRT_NUM_COUNTERS + 4, sizeof(st), hipMemcpyDeviceToHost));
+        ctx->pool_peak = std::max<uint64_t>(ctx->pool_peak, st[3]);
+        if ((uint32_t)st[1] != 0u)
+        {
+            if ((rc = redo_batches(ctx, st[2]))) return rc;
+            if ((rc = collect_timings(ctx))) return rc;
+        }
+        ctx->inflight.clear();
+    }
+    return 0;
 }
 
 extern "C" int drt_reset_film(drt_context *ctx)
@@ -1043,7 +1205,7 @@ extern "C" int drt_reset_film(drt_context *ctx)
     HIP_TRY(hipMemsetAsync(ctx->d_pixels, 0, pixels_bytes(ctx), ctx->stream));
     if (ctx->d_avgs) HIP_TRY(hipMemsetAsync(ctx->d_avgs, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
     if (ctx->d_vars) HIP_TRY(hipMemsetAsync(ctx->d_vars, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 4) * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 8) * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->trace_ms = ctx->shade_ms = 0.0;
     return 0;
@@ -1130,6 +1292,10 @@ extern "C" int drt_get_stats(drt_context *ctx, drt_stats *out)
     out->trace_ms = ctx->trace_ms;
     out->shade_ms = ctx->shade_ms;
     out->total_ms = ctx->trace_ms + ctx->shade_ms;
+    out->record_pool_blocks = ctx->pool_blocks;
+    out->record_pool_peak = ctx->pool_peak;
+    out->record_block_bytes = ctx->block_words * 8;
+    out->redone_launches = (uint32_t)ctx->redone_batches;
     return 0;
 }
 

@@ -70,7 +70,8 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("closest_hit_scans", C.c_uint64), ("shaded_vertices", C.c_uint64),
                 ("shadow_scans", C.c_uint64), ("rng_draws", C.c_uint64), ("trace_ms", C.c_double),
-                ("shade_ms", C.c_double), ("total_ms", C.c_double)]
+                ("shade_ms", C.c_double), ("total_ms", C.c_double), ("record_pool_blocks", C.c_uint64),
+                ("record_pool_peak", C.c_uint64), ("record_block_bytes", C.c_uint32), ("redone_launches", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

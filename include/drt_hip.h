@@ -188,6 +188,12 @@ typedef struct drt_stats
     double   trace_ms;          /* path-geometry kernel, HIP-event time      */
     double   shade_ms;          /* spectral shade + film kernel              */
     double   total_ms;
+    /* the pool of vertex records (four vertices per block): its size, the most a launch has used, and how many launches had to be
+     * rendered again in worst-case-sized pieces because the pool ran out (0 unless the tile's paths grew after the context measured them) */
+    uint64_t record_pool_blocks;
+    uint64_t record_pool_peak;
+    uint32_t record_block_bytes;
+    uint32_t redone_launches;
 } drt_stats;
 
 typedef struct drt_context drt_context;

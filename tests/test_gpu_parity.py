@@ -305,6 +305,42 @@ def test_long_batches_and_work_queue_shapes_do_not_change_a_bit(monkeypatch):
             assert np.array_equal(a, b), "S=64 subs %d" % subs
 
 
+def test_record_pool_that_runs_out_is_rendered_again_not_wrong(monkeypatch):
+    """Vertex records live in a pool sized from the tile's measured blocks per path. If a launch needs more (forced here with
+    a pool of one worst-case sample per pixel under launches of 12 samples), its shade kernel and everything queued behind it
+    must do nothing, and the library must render those samples again in worst-case-sized launches: same film, bit for bit,
+    same statistics apart from the wasted work, and the statistics say it happened."""
+    bundle, _ = cases.load_case("plane_light_48")
+    p = pydrt.make_params(48, 48, spp=30, max_depth=8, seed=3, batch_spp=12)
+    r = pydrt.Renderer(bundle, p)
+    r.render(0, 30)
+    px0, av0, va0 = r.read_film()
+    st0 = r.stats()
+    r.close()
+    assert st0.redone_launches == 0 and 0 < st0.record_pool_peak <= st0.record_pool_blocks
+    monkeypatch.setenv("DRT_POOL_BLOCKS", "1")
+    r = pydrt.Renderer(bundle, p)
+    r.render(0, 7)       # two calls, several launches each, queued before anything is waited for
+    r.render(7, 23)
+    px1, av1, va1 = r.read_film()
+    st1 = r.stats()
+    assert st1.redone_launches >= 2 and st1.record_pool_blocks < st0.record_pool_blocks
+    assert np.array_equal(px0, px1) and np.array_equal(av0, av1) and np.array_equal(va0, va1)
+    # and the context goes on working: more samples on top, against a fresh run of all of them
+    r.render(30, 5)
+    px2, _, va2 = r.read_film()
+    r.close()
+    monkeypatch.delenv("DRT_POOL_BLOCKS")
+    p35 = pydrt.make_params(48, 48, spp=35, max_depth=8, seed=3, batch_spp=12)
+    r = pydrt.Renderer(bundle, p35)
+    r.render(0, 35)
+    px3, _, va3 = r.read_film()
+    r.close()
+    assert np.array_equal(px2, px3) and np.array_equal(va2, va3)
+    opx, _, ova, _, _ = O.oracle_render_tile(bundle, p35, math_mode=O.MATH_DEVICE)
+    assert cases.rel_err(px3, opx) <= FILM_TOL and cases.rel_err(va3, ova) <= FILM_TOL
+
+
 def test_device_group_gives_the_single_context_film():
     """drt_group_*: one host thread, several contexts (here 1, 3 and 5 of them, all on GPU 0; 5 > the 4 rows of the last
     tile, so one context gets no rows) with the rows dealt cyclically -- film, resume and statistics equal the single
