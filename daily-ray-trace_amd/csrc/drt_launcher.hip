@@ -779,7 +779,7 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
      * shade kernel and everything queued behind it do nothing and the host renders those samples again in launches sized for the
      * worst case (redo_batches): slower, never wrong. Launch size: large launches are the efficient ones (their last round is
      * amortised: DESIGN.md, work queues); the default follows the job announced in params->spp -- about 32 kernel pairs, at least
-     * 6 GB of records, at most 64 M paths per launch -- because device memory a process touches for the first time is cleared by
+     * 16 GB of records (one-shot 1024^2 x 256 spp: 926 Mpaths/s with 6 GB, 1050 with 20-30 GB, no slower to create), at most 64 M paths per launch -- because device memory a process touches for the first time is cleared by
      * the driver (10-40 ms per GB). Callers that keep a context across many frames pass batch_spp themselves.
      */
     const size_t block_bytes = (size_t)ctx->block_words * 8;
@@ -839,7 +839,7 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     {
         const double path_bytes = 1.2 * (1.0 + 64.0 / POOL_CHUNK) * ctx->est_blocks_per_path * (double)block_bytes + (double)per_path_fixed;
         uint64_t by_job = (std::max<uint32_t>(params->spp, 1) + 31) / 32;
-        uint64_t by_floor = (uint64_t)((double)(6ull << 30) / (path_bytes * (double)npx));
+        uint64_t by_floor = (uint64_t)((double)(16ull << 30) / (path_bytes * (double)npx));
         uint64_t cap = std::max<uint64_t>(1, std::min<uint64_t>(DRT_DEFAULT_MAX_BATCH, (64ull << 20) / npx));
         batch = (uint32_t)std::max<uint64_t>(1, std::min(std::max(by_job, by_floor), cap));
         if (params->spp) batch = std::min(batch, params->spp);
@@ -1326,6 +1326,21 @@ extern "C" int drt_render_tile(const drt_scene *scene, const drt_camera *camera,
         if (!(params->flags & DRT_FLAG_FILM_ZERO) && (rc = drt_write_film(ctx, dst_pixels, dst_avgs, dst_vars))) break;
         t[2] = wall_ms();
         if ((rc = drt_render(ctx, params->first_sample, params->spp))) break;
+        if (params->flags & DRT_FLAG_FILM_ZERO)
+        {
+            /* Buffers that come zero-filled (the reference's alloc()) have usually never been touched: the download would then
+             * pay a page fault per 4 KB (100 ms for 1.7 GB instead of 30). The kernels are running and this thread has nothing to
+             * do, so it touches the pages now -- writing the zero the caller vouched for into one byte of each. */
+            const size_t n = (size_t)params->tile_w * params->tile_h, S = scene->num_wavelengths;
+            char *bufs[3] = {(char *)dst_pixels, (char *)dst_avgs, (char *)dst_vars};
+            const size_t sizes[3] = {n * (xyz ? (size_t)XYZ_FILM_WORDS : S + 1) * 8, n * S * 8, n * S * 8};
+            for (int k = 0; k < 3; k += 1)
+            {
+                if (!bufs[k]) continue;
+                for (size_t off = 0; off < sizes[k]; off += 4096) ((volatile char *)bufs[k])[off] = 0;
+                if (sizes[k]) ((volatile char *)bufs[k])[sizes[k] - 1] = 0;
+            }
+        }
         if (verbose && (rc = drt_synchronize(ctx))) break;
         t[3] = wall_ms();
         if ((rc = drt_read_film(ctx, dst_pixels, dst_avgs, dst_vars))) break;

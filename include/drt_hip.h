@@ -165,9 +165,9 @@ typedef struct drt_params
     uint64_t seed;
     uint32_t mode;         /* DRT_MODE_* */
     int32_t  device;       /* HIP device ordinal */
-    uint32_t batch_spp;    /* samples traced per launch pair. 0 = sized for a job of `spp` samples (about 32 launch pairs, >= 1 GB of
-                              path records); a context kept across many frames does better with 64 M paths per launch:
-                              batch_spp = min(256, (64 << 20) / (tile_w * tile_h)) */
+    uint32_t batch_spp;    /* samples traced per launch pair. 0 = sized for a job of `spp` samples (about 32 launch pairs, or as many samples
+                              as about 16 GB of vertex records hold, whichever is more); a context kept across many frames does best
+                              with 64 M paths per launch: batch_spp = min(256, (64 << 20) / (tile_w * tile_h)) */
     uint32_t flags;        /* DRT_FLAG_* */
 } drt_params;
 
