@@ -1052,6 +1052,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
 #define DRT_SHADE_WAVES_PER_SIMD 4
 #endif
 #define SHADE_WAVES (SHADE_BLOCK / 64)
+/* one wavelength set per lane fits 128 registers (4 waves per SIMD); two or more sets hold two or more of every per-wavelength
+ * value and spill at that budget (116-250 bytes of scratch): they get the registers of 3 or 2 waves per SIMD instead */
+#ifndef DRT_SHADE_WAVES_MULTISET
+#define DRT_SHADE_WAVES_MULTISET(n) ((n) == 2 ? 3 : 2)
+#endif
+#define SHADE_WAVES_PER_SIMD_FOR(n) ((n) == 1 ? DRT_SHADE_WAVES_PER_SIMD : DRT_SHADE_WAVES_MULTISET(n))
 #define SHADE_MAX_SETS 4 /* wavelengths per lane: S <= 64 * SHADE_MAX_SETS */
 
 struct ShadeParams
@@ -1377,7 +1383,7 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
 
 
 template <int NSETS, bool SPDS_IN_LDS, bool XYZ>
-__global__ __launch_bounds__(SHADE_BLOCK, DRT_SHADE_WAVES_PER_SIMD) void drt_shade_kernel(DevScene sc, ShadeParams sp, const uint64_t *__restrict__ records,
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void drt_shade_kernel(DevScene sc, ShadeParams sp, const uint64_t *__restrict__ records,
                                                                  const uint64_t *__restrict__ headers, double *__restrict__ film_pixels,
                                                                  double *__restrict__ film_avgs, double *__restrict__ film_vars,
                                                                  unsigned long long *__restrict__ work_counter)
