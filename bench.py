@@ -287,9 +287,9 @@ def main():
         if brows == 0:
             renderers.append(None)
             continue
-        # contexts live across all the steps, so launches are sized for throughput (64 M paths per kernel pair, drt_hip.h), not
-        # for the one frame `spp` announces
-        batch = args.batch if args.batch > 0 else max(1, min(256, args.spp, (64 << 20) // max(brows * W, 1)))
+        # contexts live across all the steps, so launches are sized for throughput (DRT_BATCH_RESIDENT: 64 M paths per kernel pair,
+        # at least 16 samples per pixel), not for the one frame `spp` announces
+        batch = args.batch if args.batch > 0 else pydrt.BATCH_RESIDENT
         params = pydrt.make_params(W, H, spp=args.spp, max_depth=args.depth, seed=1, y0=by0, tile_h=brows, row_stride=bstride,
                                    device=local_rank, batch_spp=batch, mode=pydrt.MODE_XYZ if xyz else pydrt.MODE_SPECTRAL)
         r = pydrt.Renderer(bundle, params)

@@ -835,7 +835,16 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
         return std::max<uint64_t>(std::min<uint64_t>(expect, blocks_worst_case(ctx, n_paths)), blocks_worst_case(ctx, npx));
     };
     uint32_t batch = params->batch_spp;
-    if (batch == 0)
+    if (batch == DRT_BATCH_RESIDENT)
+    {
+        /* a context kept across many frames: 64 M paths per kernel pair keep the launches' last rounds short (work
+         * queues) -- but never fewer than 16 samples per pixel and launch where memory allows, because the film is read and written
+         * once per launch: 3328 bytes per pixel, which at 4 samples a launch (the 4096^2 frame of config 5) was a third of the frame */
+        const uint64_t by_paths = std::max<uint64_t>(1, std::min<uint64_t>(DRT_DEFAULT_MAX_BATCH, (64ull << 20) / npx));
+        batch = (uint32_t)std::max<uint64_t>(by_paths, 16);
+        if (params->spp) batch = std::min(batch, params->spp);
+    }
+    else if (batch == 0)
     {
         const double path_bytes = 1.2 * (1.0 + 64.0 / POOL_CHUNK) * ctx->est_blocks_per_path * (double)block_bytes + (double)per_path_fixed;
         uint64_t by_job = (std::max<uint32_t>(params->spp, 1) + 31) / 32;

@@ -19,6 +19,7 @@ GEO_POINT, GEO_SPHERE, GEO_PLANE = 1, 2, 3
 FILM_SAMPLE_CENTER, FILM_SAMPLE_RANDOM = 1, 2
 MODE_SPECTRAL, MODE_XYZ = 0, 1
 FLAG_RECORD_HITS = 1
+BATCH_RESIDENT = 0xFFFFFFFF  # make_params(batch_spp=...): launches sized for a context kept across frames
 FLAG_FILM_ZERO = 2
 
 # names and order of include/bdsf_list.h

@@ -166,10 +166,12 @@ typedef struct drt_params
     uint32_t mode;         /* DRT_MODE_* */
     int32_t  device;       /* HIP device ordinal */
     uint32_t batch_spp;    /* samples traced per launch pair. 0 = sized for a job of `spp` samples (about 32 launch pairs, or as many samples
-                              as about 16 GB of vertex records hold, whichever is more); a context kept across many frames does best
-                              with 64 M paths per launch: batch_spp = min(256, (64 << 20) / (tile_w * tile_h)) */
+                              as about 16 GB of vertex records hold, whichever is more); DRT_BATCH_RESIDENT = sized for a context kept across
+                              many frames (64 M paths per launch, at least 16 samples per pixel, as memory allows) */
     uint32_t flags;        /* DRT_FLAG_* */
 } drt_params;
+
+#define DRT_BATCH_RESIDENT 0xFFFFFFFFu /* drt_params.batch_spp: let the library size launches for a long-lived context */
 
 enum
 {

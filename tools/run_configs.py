@@ -17,7 +17,10 @@ for name, load, size, spp, depth in configs:
     if only and not name.startswith(only):
         continue
     b = load()
-    p = pydrt.make_params(size, size, spp=spp, max_depth=depth, seed=1, batch_spp=max(1, min(256, spp, (64 << 20) // (size * size))))  # long-lived context sizing
+    batch = pydrt.BATCH_RESIDENT  # long-lived context sizing (include/drt_hip.h)
+    if os.environ.get("BATCH"):
+        batch = int(os.environ["BATCH"])
+    p = pydrt.make_params(size, size, spp=spp, max_depth=depth, seed=1, batch_spp=batch)
     r = pydrt.Renderer(b, p)
     r.render(0, min(spp, r.batch_spp())); r.synchronize(); r.reset_film()
     t0 = time.time(); r.render(0, spp); r.synchronize(); t1 = time.time()
