@@ -1857,6 +1857,65 @@ __global__ void drt_film_xyz_kernel(DevScene sc, uint32_t cmf_rw, uint32_t cmf_x
     xyz[3 * p + 2] = Z * (interval / n);
 }
 
+/*
+ * Film -> the pixel bytes of the reference's .bmp outputs, on the device: spd_file_to_rgb_f64_pixels
+ * (src/daily_ray_trace.c:1-28: divide by the filter sum when the buffer carries one), spectrum_to_xyz and the fixed XYZ -> linear RGB
+ * matrix (src/spectrum.c:49-82), rgb_f64_to_rgb_u8 (src/win32_platform.c:136-147: clamp to [0,1], x 255, truncate; no gamma), stored
+ * B, G, R, A as write_pixels_to_bmp lays them out (the alpha byte the reference leaves unset is 255). `which`: 0 = sum (/ filter),
+ * 1 = running mean, 2 = variance divided by its largest sample (spectrum_normalise, src/spectrum.c:182-187, which render_image
+ * applies before writing the variance file: src/daily_ray_trace.c:766-768). Same expressions in the same order as
+ * host/drt_bmp.c, no contraction: the bytes are equal to the host path's.
+ */
+__global__ void drt_film_bgra_kernel(DevScene sc, uint32_t cmf_rw, uint32_t cmf_x, uint32_t cmf_y, uint32_t cmf_z, double interval,
+                                     uint64_t n_pix, const double *__restrict__ film, int which, uint8_t *__restrict__ bgra)
+{
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pix) return;
+    const uint32_t S = sc.S;
+    const double *rw = sc.spds + (size_t)cmf_rw * S, *cx = sc.spds + (size_t)cmf_x * S;
+    const double *cy = sc.spds + (size_t)cmf_y * S, *cz = sc.spds + (size_t)cmf_z * S;
+    const double *px = film + p * (uint64_t)(which == 0 ? S + 1 : S);
+    double div = 1.0;
+    bool divide = false;
+    if (which == 0) { div = px[S]; divide = true; }
+    if (which == 2)
+    {
+        double highest = 0.0;
+        for (uint32_t i = 0; i < S; i += 1) if (px[i] > highest) highest = px[i];
+        div = highest;
+        divide = true;
+    }
+    double n = 0.0;
+    for (uint32_t i = 0; i < S; i += 1) n += (cy[i] * rw[i]);
+    n *= interval;
+    double X = 0.0, Y = 0.0, Z = 0.0;
+    for (uint32_t i = 0; i < S; i += 1)
+    {
+        double v = divide ? px[i] / div : px[i];
+        X += (cx[i] * v * rw[i]);
+        Y += (cy[i] * v * rw[i]);
+        Z += (cz[i] * v * rw[i]);
+    }
+    X *= (interval / n);
+    Y *= (interval / n);
+    Z *= (interval / n);
+    double rgb[3];
+    rgb[0] = (2.3706743 * X) - (0.9000405 * Y) - (0.4706338 * Z);
+    rgb[1] = (-0.5138850 * X) + (1.4253036 * Y) + (0.0885814 * Z);
+    rgb[2] = (0.0052982 * X) - (0.0146949 * Y) + (1.0093968 * Z);
+    uint8_t out[3];
+    for (int c = 0; c < 3; c += 1)
+    {
+        double f = rgb[c];
+        f = (f < 0.0) ? 0.0 : f;
+        f = (f > 1.0) ? 1.0 : f;
+        out[c] = (f == f) ? (uint8_t)(f * 255.0) : (uint8_t)0; /* a NaN (0/0 in a pixel no path reached) converts to 0 on x86 too */
+    }
+    uchar4 o;
+    o.x = out[2]; o.y = out[1]; o.z = out[0]; o.w = 255;
+    ((uchar4 *)bgra)[p] = o;
+}
+
 /* XYZ film mode: accumulators -> per-pixel XYZ, the same normalisation as above (src/spectrum.c:52-69) */
 __global__ void drt_xyz_finish_kernel(DevScene sc, uint32_t cmf_rw, uint32_t cmf_y, double interval, uint64_t n_pix,
                                       const double *__restrict__ film, double *__restrict__ xyz)

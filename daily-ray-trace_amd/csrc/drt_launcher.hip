@@ -76,6 +76,7 @@ struct drt_context
     bool        bvh_pipeline = false;
     int         primary_grid_cap = 0, bounce_grid_cap = 0;
     double   *d_xyz = nullptr;
+    uint8_t  *d_bgra = nullptr;
 
     bool   scene_in_lds = true, spds_in_lds = true, use_bvh = false;
     size_t trace_lds = 0, shade_lds = 0;
@@ -916,6 +917,7 @@ extern "C" void drt_destroy(drt_context *ctx)
     (void)hipFree(ctx->d_hits);
     (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_xyz);
+    (void)hipFree(ctx->d_bgra);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -1274,6 +1276,30 @@ extern "C" int drt_read_xyz(drt_context *ctx, double *xyz)
     return 0;
 }
 
+/* one film buffer as BMP pixel bytes, left on the device in ctx->d_bgra */
+static int film_to_bgra(drt_context *ctx, int which)
+{
+    if (which < 0 || which > 2) return fail(-1, "which = %d: 0 sum, 1 mean, 2 variance", which);
+    if (ctx->xyz_mode) return fail(-4, "the XYZ film keeps no spectra: render in DRT_MODE_SPECTRAL for .bmp pixels");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->d_bgra) HIP_TRY(hipMalloc((void **)&ctx->d_bgra, (size_t)ctx->n_pix * 4));
+    const double *film = which == 0 ? ctx->d_pixels : which == 1 ? ctx->d_avgs : ctx->d_vars;
+    uint32_t grid = (uint32_t)((ctx->n_pix + 255) / 256);
+    hipLaunchKernelGGL(drt_film_bgra_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->dsc, ctx->cmf_rw, ctx->cmf_x, ctx->cmf_y,
+                       ctx->cmf_z, ctx->interval, ctx->n_pix, film, which, ctx->d_bgra);
+    HIP_TRY(hipGetLastError());
+    return drt_synchronize(ctx);
+}
+
+extern "C" int drt_read_bgra(drt_context *ctx, int which, uint8_t *bgra)
+{
+    if (!ctx || !bgra) return fail(-1, "null argument");
+    int rc = film_to_bgra(ctx, which);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(bgra, ctx->d_bgra, (size_t)ctx->n_pix * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int drt_read_hit_indices(drt_context *ctx, int32_t *dst, uint64_t capacity_paths)
 {
     if (!ctx || !dst) return fail(-1, "null argument");
@@ -1511,6 +1537,22 @@ extern "C" int drt_group_write_film(drt_group *g, const double *pixels, const do
     if ((rc = group_copy(g, const_cast<double *>(pixels), 0, true))) return rc;
     if ((rc = group_copy(g, const_cast<double *>(avgs), 1, true))) return rc;
     return group_copy(g, const_cast<double *>(vars), 2, true);
+}
+
+extern "C" int drt_group_read_bgra(drt_group *g, int which, uint8_t *bgra)
+{
+    if (!g || !bgra) return fail(-1, "null argument");
+    const size_t n = g->ctx.size();
+    const size_t row_bytes = (size_t)g->tile_w * 4;
+    for (size_t k = 0; k < n; k += 1)
+    {
+        drt_context *c = g->ctx[k];
+        if (!c) continue;
+        int rc = film_to_bgra(c, which);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy2D(bgra + k * row_bytes, n * row_bytes, c->d_bgra, row_bytes, row_bytes, g->rows[k], hipMemcpyDeviceToHost));
+    }
+    return 0;
 }
 
 extern "C" int drt_group_get_stats(drt_group *g, drt_stats *out)

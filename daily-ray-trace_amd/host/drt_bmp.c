@@ -49,18 +49,17 @@ void drt_host_spectrum_to_rgb(const f64 *cmf, u32 S, f64 interval, const f64 *sp
     rgb[2] = (0.0052982 * X) - (0.0146949 * Y) + (1.0093968 * Z);
 }
 
-int drt_host_write_bmp(const char *path, u32 width, u32 height, const f64 *rgb /* [h*w][3], row 0 first */)
+/* headers + 4 bytes per pixel (B, G, R, A; row 0 first), write_pixels_to_bmp (src/win32_platform.c:11-41) */
+int drt_host_write_bmp_bgra(const char *path, u32 width, u32 height, const u8 *bgra)
 {
     size_t n = (size_t)width * height;
-    size_t size = sizeof(bmp_file_header) + sizeof(bmp_info_header) + n * 4;
-    u8 *raw = (u8 *)calloc(size, 1);
-    if (!raw) return -1;
-    bmp_file_header *fh = (bmp_file_header *)raw;
-    bmp_info_header *ih = (bmp_info_header *)(raw + sizeof(bmp_file_header));
-    u8 *px = raw + sizeof(bmp_file_header) + sizeof(bmp_info_header);
+    u8 head[sizeof(bmp_file_header) + sizeof(bmp_info_header)];
+    memset(head, 0, sizeof(head));
+    bmp_file_header *fh = (bmp_file_header *)head;
+    bmp_info_header *ih = (bmp_info_header *)(head + sizeof(bmp_file_header));
     fh->bfType = 0x4d42;
-    fh->bfSize = (uint32_t)size;
-    fh->bfOffBits = sizeof(bmp_file_header) + sizeof(bmp_info_header);
+    fh->bfSize = (uint32_t)(sizeof(head) + n * 4);
+    fh->bfOffBits = sizeof(head);
     ih->biSize = sizeof(bmp_info_header);
     ih->biWidth = (int32_t)width;
     ih->biHeight = (int32_t)height; /* positive: bottom-up, and pixel row 0 is the bottom of the film */
@@ -68,6 +67,18 @@ int drt_host_write_bmp(const char *path, u32 width, u32 height, const f64 *rgb /
     ih->biBitCount = 32;
     ih->biXPelsPerMeter = 3780;
     ih->biYPelsPerMeter = 3780;
+    FILE *f = fopen(path, "wb");
+    if (!f) return -2;
+    int ok = fwrite(head, 1, sizeof(head), f) == sizeof(head) && fwrite(bgra, 1, n * 4, f) == n * 4;
+    ok = (fclose(f) == 0) && ok;
+    return ok ? 0 : -3;
+}
+
+int drt_host_write_bmp(const char *path, u32 width, u32 height, const f64 *rgb /* [h*w][3], row 0 first */)
+{
+    size_t n = (size_t)width * height;
+    u8 *px = (u8 *)malloc(n * 4 + 4);
+    if (!px) return -1;
     for (size_t i = 0; i < n; i += 1)
     {
         px[4 * i + 2] = (u8)(clamp01(rgb[3 * i + 0]) * 255.0);
@@ -75,12 +86,9 @@ int drt_host_write_bmp(const char *path, u32 width, u32 height, const f64 *rgb /
         px[4 * i + 0] = (u8)(clamp01(rgb[3 * i + 2]) * 255.0);
         px[4 * i + 3] = 255;
     }
-    FILE *f = fopen(path, "wb");
-    if (!f) { free(raw); return -2; }
-    int ok = fwrite(raw, 1, size, f) == size;
-    fclose(f);
-    free(raw);
-    return ok ? 0 : -3;
+    int rc = drt_host_write_bmp_bgra(path, width, height, px);
+    free(px);
+    return rc;
 }
 
 /* spd_file_to_bmp, src/win32_main.c:115-121 */

@@ -166,6 +166,7 @@ const char *drt_host_checkpoint_error(void);
 /* .spd -> BMP post-process (spd_file_to_bmp, src/win32_main.c:115-121). cmf: [4][S] rows rw, x, y, z. */
 void drt_host_spectrum_to_rgb(const f64 *cmf, u32 S, f64 interval, const f64 *spd, f64 rgb[3]);
 int  drt_host_write_bmp(const char *path, u32 width, u32 height, const f64 *rgb);
+int  drt_host_write_bmp_bgra(const char *path, u32 width, u32 height, const u8 *bgra);
 int  drt_host_spd_file_to_bmp(const char *spd_path, const char *bmp_path, const f64 *cmf);
 
 #ifdef __cplusplus

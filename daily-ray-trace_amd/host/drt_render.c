@@ -127,11 +127,27 @@ int render_image_ex(config_arguments *config, const drt_host_options *opt, drt_s
     }
     if (!rc) rc = drt_group_read_film(ctx, dst_pixels, dst_avgs, dst_vars);
     if (!rc) rc = drt_group_get_stats(ctx, &stats);
+    /* the .bmp pixels come from the film while it is still on the device (drt_read_bgra: the same bytes as converting the
+     * .spd files on the host, host/drt_bmp.c, without reading 1.7 GB back from disk) */
+    u8 *bgra[3] = { NULL, NULL, NULL };
+    const char *bmp_path[3] = { config->output_bmp, config->average_bmp, config->variance_bmp };
+    for (int k = 0; !rc && k < 3 && config->output_bmp[0]; k += 1)
+    {
+        if (!bmp_path[k][0]) continue;
+        bgra[k] = (u8 *)malloc(num_pixels * 4 + 4);
+        if (!bgra[k]) { rc = -3; break; }
+        rc = drt_group_read_bgra(ctx, k, bgra[k]);
+    }
     drt_group_destroy(ctx);
     f64 t1 = now_ms();
     if (rc != 0)
     {
         fprintf(stderr, "render_image: the HIP launcher failed (%d): %s\n", rc, drt_last_error());
+        for (int k = 0; k < 3; k += 1) free(bgra[k]);
+        free(dst_vars);
+        free(dst_avgs);
+        free(dst_pixels);
+        drt_host_free_scene(hs);
         return rc;
     }
     if (!(opt && opt->quiet))
@@ -147,15 +163,15 @@ int render_image_ex(config_arguments *config, const drt_host_options *opt, drt_s
                                      (opt && opt->checkpoint_spp) ? 1 : 0, done, seed);
     if (wrc) fprintf(stderr, "render_image: %s\n", drt_host_checkpoint_error());
     int w0 = wrc, w1 = 0, w2 = 0;
-    /* post-process like the reference's main(): each .spd -> linear RGB -> BMP (src/win32_main.c:150-152) */
-    if (!(w0 || w1 || w2) && config->output_bmp[0])
+    /* post-process like the reference's main(): each film -> linear RGB -> BMP (src/win32_main.c:150-152) */
+    if (!(w0 || w1 || w2))
     {
-        const f64 *cmf = scene->spds + (size_t)scene->cmf_rw * S; /* rows rw, x, y, z are adjacent (host/drt_scene.c) */
-        int b0 = drt_host_spd_file_to_bmp(config->output_spd, config->output_bmp, cmf);
-        int b1 = config->average_bmp[0] ? drt_host_spd_file_to_bmp(config->average_spd, config->average_bmp, cmf) : 0;
-        int b2 = config->variance_bmp[0] ? drt_host_spd_file_to_bmp(config->variance_spd, config->variance_bmp, cmf) : 0;
-        if (b0 || b1 || b2) fprintf(stderr, "render_image: could not write one of the .bmp outputs\n");
+        int bad = 0;
+        for (int k = 0; k < 3; k += 1)
+            if (bgra[k]) bad |= drt_host_write_bmp_bgra(bmp_path[k], width, height, bgra[k]);
+        if (bad) fprintf(stderr, "render_image: could not write one of the .bmp outputs\n");
     }
+    for (int k = 0; k < 3; k += 1) free(bgra[k]);
     if (stats_out) *stats_out = stats;
     free(dst_vars);
     free(dst_avgs);

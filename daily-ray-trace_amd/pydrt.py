@@ -301,6 +301,8 @@ def hip_lib():
         L.drt_film_device_ptrs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         L.drt_read_film.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.drt_read_xyz.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.drt_read_bgra.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint8)]
+        L.drt_group_read_bgra.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint8)]
         f64p, i32p = C.POINTER(C.c_double), C.POINTER(C.c_int32)
         L.drt_group_create.restype = C.c_void_p
         L.drt_group_create.argtypes = [C.POINTER(Scene), C.POINTER(Camera), C.POINTER(Params), i32p, C.c_uint32]
@@ -333,10 +335,10 @@ def hip_lib():
 
 HIP_SYMBOLS = ["drt_last_error", "drt_device_count", "drt_create", "drt_destroy", "drt_bind_film", "drt_set_stream",
                "drt_render", "drt_synchronize", "drt_reset_film", "drt_film_device_ptrs", "drt_read_film", "drt_write_film",
-               "drt_read_xyz", "drt_read_hit_indices", "drt_get_stats", "drt_batch_spp", "drt_render_tile", "drt_selftest_arith",
+               "drt_read_xyz", "drt_read_bgra", "drt_read_hit_indices", "drt_get_stats", "drt_batch_spp", "drt_render_tile", "drt_selftest_arith",
                "drt_selftest_unit", "drt_bvh_stats",
                "drt_group_create", "drt_group_destroy", "drt_group_size", "drt_group_render", "drt_group_synchronize",
-               "drt_group_read_film", "drt_group_write_film", "drt_group_get_stats", "drt_render_tile_multi"]
+               "drt_group_read_film", "drt_group_write_film", "drt_group_read_bgra", "drt_group_get_stats", "drt_render_tile_multi"]
 
 
 def _check(rc, what):
@@ -415,6 +417,12 @@ class Renderer:
         xyz = np.empty((self.n_pixels, 3), dtype=np.float64)
         _check(self.L.drt_read_xyz(self.ctx, _ptr(xyz, C.c_double)), "drt_read_xyz")
         return xyz
+
+    def read_bgra(self, which=0):
+        """BMP pixel bytes [n][4] = B, G, R, 255 of the sum (0), mean (1) or normalised variance (2) film."""
+        out = np.empty((self.n_pixels, 4), dtype=np.uint8)
+        _check(self.L.drt_read_bgra(self.ctx, int(which), _ptr(out, C.c_uint8)), "drt_read_bgra")
+        return out
 
     def read_hit_indices(self, num_samples):
         n = self.n_pixels * num_samples

@@ -227,6 +227,11 @@ int drt_read_film(drt_context *ctx, double *pixels, double *avgs, double *vars);
 int drt_write_film(drt_context *ctx, const double *pixels, const double *avgs, const double *vars);
 /* Per-pixel XYZ of sum/filter (spectrum_to_xyz on the device), [tile_h*tile_w][3]. Synchronises. */
 int drt_read_xyz(drt_context *ctx, double *xyz);
+/* One film buffer as the pixel bytes of the reference's .bmp outputs, [tile_h*tile_w][4] = B, G, R, 255, tile row 0 first (the
+ * order a bottom-up BMP stores them): which = 0 sum / filter, 1 running mean, 2 variance / its largest sample. Replaces
+ * spd_file_to_rgb_f64_pixels (src/daily_ray_trace.c:1-28) + spectrum_to_rgb_f64 (src/spectrum.c:72-82) + rgb_f64_to_rgb_u8
+ * (src/win32_platform.c:136-147) with one kernel over the resident film. DRT_MODE_SPECTRAL only. Synchronises. */
+int drt_read_bgra(drt_context *ctx, int which, uint8_t *bgra);
 /* Closest-hit surface indices of the LAST rendered sample batch: [n][max_depth] int32 per path
  * (-1 miss, -2 vertex not reached); needs DRT_FLAG_RECORD_HITS. Paths are ordered
  * (sample - first_sample_of_last_call, tile row, tile column). */
@@ -263,6 +268,7 @@ int drt_group_synchronize(drt_group *g);
 /* Whole-tile film buffers ([tile_h*tile_w][S+1], [..][S], [..][S]) <-> the devices' row sets. NULL skips a buffer. */
 int drt_group_read_film(drt_group *g, double *pixels, double *avgs, double *vars);
 int drt_group_write_film(drt_group *g, const double *pixels, const double *avgs, const double *vars);
+int drt_group_read_bgra(drt_group *g, int which, uint8_t *bgra); /* drt_read_bgra over the whole image */
 /* Counters summed over the devices; trace_ms / shade_ms / total_ms are the slowest device's. */
 int drt_group_get_stats(drt_group *g, drt_stats *out);
 /* One-shot form of drt_render_tile over a device list. */

@@ -409,6 +409,8 @@ def test_xyz_film_mode_matches_the_spectral_film(name):
         assert (st.paths, st.rng_draws) == (spectral[5].paths, spectral[5].rng_draws)
         with pytest.raises(RuntimeError):
             r.read_film()
+        with pytest.raises(RuntimeError, match="DRT_MODE_SPECTRAL"):
+            r.read_bgra(0)
         r.close()
         if batch == 0:
             acc0 = acc
@@ -700,6 +702,20 @@ def test_drt_render_program_checkpoint_and_resume(tmp_path):
     assert "Rendering on 3 devices" in out3 and "Checkpoint at 4 / 6 samples" in out3
     for f in ("output.spd", "average.spd", "variance.spd", "output.bmp"):
         assert open(os.path.join(a, "output", f), "rb").read() == open(os.path.join(c, "output", f), "rb").read(), f
+    # N2 on the device: the three .bmp files (drt_read_bgra on the resident film) are byte for byte what the host conversion of the
+    # written .spd files gives (host/drt_bmp.c, whose arithmetic is pinned to the reference's spectrum_to_rgb_f64 in tests/test_host.py)
+    H = pydrt.host_lib()
+    f64p = C.POINTER(C.c_double)
+    H.drt_host_spd_file_to_bmp.argtypes = [C.c_char_p, C.c_char_p, f64p]
+    bundle96 = pydrt.load_scene(cases.scene_path("cornell_plane_light.scn"), 96, 64)
+    cmf = np.ascontiguousarray(bundle96.spds()[int(bundle96.scene.cmf_rw):int(bundle96.scene.cmf_rw) + 4])  # rows rw, x, y, z
+    for name in ("output", "average", "variance"):
+        for d in (a, c):
+            host_bmp = os.path.join(d, "output", name + "_host.bmp")
+            assert H.drt_host_spd_file_to_bmp(os.path.join(d, "output", name + ".spd").encode(), host_bmp.encode(), cmf.ctypes.data_as(f64p)) == 0
+            dev = open(os.path.join(d, "output", name + ".bmp"), "rb").read()
+            assert len(dev) == 54 + 96 * 64 * 4 and dev == open(host_bmp, "rb").read(), (name, d)
+    assert len(set(open(os.path.join(a, "output", "output.bmp"), "rb").read()[54:])) > 50  # a picture, not a constant
     # and the film agrees with the oracle
     hdr = np.fromfile(os.path.join(a, "output", "output.spd"), dtype=np.uint32, count=5)
     assert list(hdr[1:5]) == [96, 64, 69, 1]
