@@ -5,8 +5,9 @@ sys.path.insert(0, os.path.join(REPO, "daily-ray-trace_amd"))
 import pydrt
 spp = int(os.environ.get("SPP", "16")); batch = int(os.environ.get("BATCH", "8")); size = int(os.environ.get("SIZE", "1024"))
 depth = int(os.environ.get("DEPTH", "8"))
+max_wl = float(os.environ.get("MAX_WL", "720"))  # 695: a 64-sample grid, the shade kernel without its tail pass
 spheres = int(os.environ.get("SPHERES", "0"))  # > 0: BASELINE config 5's generator instead of the Cornell box
-bundle = pydrt.synthetic_sphere_scene(spheres, size, size) if spheres else pydrt.load_scene(os.path.join(REPO, "scenes", "cornell_plane_light.scn"), size, size)
+bundle = pydrt.synthetic_sphere_scene(spheres, size, size) if spheres else pydrt.load_scene(os.path.join(REPO, "scenes", "cornell_plane_light.scn"), size, size, min_wl=380.0, max_wl=max_wl, wl_interval=5.0)
 params = pydrt.make_params(size, size, spp=spp, max_depth=depth, seed=1, batch_spp=batch)
 r = pydrt.Renderer(bundle, params)
 r.render(0, batch); r.synchronize(); r.reset_film()
