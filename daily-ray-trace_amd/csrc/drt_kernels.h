@@ -1186,6 +1186,9 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
 #ifndef SHADE_PREFETCH_DEPTH
 #define SHADE_PREFETCH_DEPTH 2 /* samples whose record loads are in flight ahead of the one being replayed */
 #endif
+#ifndef DRT_SHADE_PLASTIC_RUN
+#define DRT_SHADE_PLASTIC_RUN 1 /* the leading plastic vertices of a path in a loop of their own (one light, one set) */
+#endif
 #ifndef DRT_SHADE_LDS_WORDS
 #define DRT_SHADE_LDS_WORDS 1 /* plastic vertices read their coefficient words from LDS (broadcast loads) instead of v_readlane pairs */
 #endif
@@ -1567,7 +1570,56 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                 throughput[k] = 1.0; /* const_spectrum(throughput, 1.0), :440 */
                 dst[k] = 0.0;
             }
-            for (uint32_t v = 0; v < n_shaded; v += 1)
+            uint32_t v_first = 0; /* vertices [0, v_first) are done by the loop for plastic runs below */
+#if DRT_SHADE_LDS_WORDS && DRT_SHADE_PLASTIC_RUN
+            if (NSETS == 1 && sp.n_lights == 1u && vpr != 0u)
+            {
+                /* The path's leading run of two-lobe plastic vertices -- most paths are nothing else -- in a loop of its own: the header's
+                 * flags say how long the run is before a word of a record is decoded, so per vertex there is one word to lift to the
+                 * scalar side (the SPD indices), one bit to test (light 0 visible), five LDS reads and the arithmetic; none of the
+                 * general loop's questions (which register? plastic? how many lights? beyond the prefetch?). Same operations in the
+                 * same order as plastic_vertex below. Measured and left out: issuing a vertex's LDS reads a vertex ahead, which this
+                 * shape allows (113.7 against 113.5 ms), and taking the later runs of a path the same way (116.2). */
+                uint32_t run = (uint32_t)__builtin_ctz(~plastic_mask | 0x10000u); /* leading plastic vertices (<= 16) */
+                run = run < n_shaded ? run : n_shaded;
+                run = run < n_fast ? run : n_fast;
+                run = run < 8u ? run : 8u; /* vis0_mask has 8 bits */
+                if (run != 0u)
+                {
+                    const double *table1 = SPDS_IN_LDS ? (const double *)lds : sc.spds;
+                    const double em0 = spd_at(table1, S, sp.light0_em_spd, lam_c[0]);
+                    for (uint32_t v = 0; v < run; v += 1)
+                    {
+                        const uint32_t idx = (v * vw + 1u) & 63u;
+                        const uint64_t wa = readlane64(cur[0], idx);
+                        const uint64_t wb = readlane64(cur[SHADE_PREFETCH_REGS > 1 ? 1 : 0], idx);
+                        const uint64_t w1 = (v < vpr) ? wa : wb;
+                        const double diffuse_pi = spd_at(table1, S, (uint32_t)(w1 >> 16) & 0xFFFFu, lam_c[0]);
+                        const double glossy = spd_at(table1, S, (uint32_t)(w1 >> 32) & 0xFFFFu, lam_c[0]);
+                        const uint64_t *vwords = rec_words + v * vw;
+                        const double dir_pdf = word_as_double(vwords[4]), s_a_in = word_as_double(vwords[5]), s_spec = word_as_double(vwords[6]);
+                        const double c = word_as_double(vwords[REC_VERTEX_WORDS + 1]), a_in = word_as_double(vwords[REC_VERTEX_WORDS + 2]);
+                        const double spec = word_as_double(vwords[REC_VERTEX_WORDS + 3]);
+                        double contribution = 0.0;
+                        if ((vis0_mask >> v) & 1u)
+                        {
+                            double reflectance = diffuse_pi * a_in + 0.0;
+                            reflectance = (glossy * spec) * a_in + reflectance;
+                            contribution = contribution + reflectance; /* :323 */
+                            contribution = contribution * em0;         /* :324 */
+                            contribution = contribution * c;           /* :326-327 */
+                        }
+                        dst[0] = dst[0] + throughput[0] * contribution; /* :461-462 */
+                        double reflectance = diffuse_pi * s_a_in + 0.0;
+                        reflectance = (glossy * s_spec) * s_a_in + reflectance;
+                        reflectance = reflectance * dir_pdf;         /* :468 */
+                        throughput[0] = throughput[0] * reflectance; /* :469 */
+                    }
+                    v_first = run;
+                }
+            }
+#endif
+            for (uint32_t v = v_first; v < n_shaded; v += 1)
             {
                 /* the register (and the lane offset in it) that holds this vertex's record */
                 uint64_t src;

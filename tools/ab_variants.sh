@@ -3,5 +3,5 @@
 for lib in daily-ray-trace_amd/libdrt_hip.so variants/*.so; do
   DRT_HIP_LIB=$PWD/$lib timeout -k 10 200 python bench.py --no-cpu-baseline --no-oneshot 2>/dev/null | python -c "
 import sys, json
-j = json.loads([l for l in sys.stdin if l[0] == chr(123)][0]); print('$lib', j['value'], j['roofline']['kernel_ms_per_step'])"
+j = json.loads(([l for l in sys.stdin if l[0] == chr(123)] or ["{\"value\": null, \"roofline\": {\"kernel_ms_per_step\": null}}"])[0]); print('$lib', j['value'], j['roofline']['kernel_ms_per_step'])"
 done
