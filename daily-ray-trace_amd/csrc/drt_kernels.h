@@ -1235,6 +1235,10 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
     uint32_t v = 0, n_shaded = 0, term = 0, term_spd = 0, plastic_mask = 0;
     double vignette = 0.0, throughput = 1.0, dst = 0.0;
     uint64_t ph2 = 0, ph3 = 0; /* the path's block words */
+    const uint64_t *vcur = records; /* the record of vertex v */
+    uint32_t vis0 = 0;          /* the header's "light 0 visible" bits (vertices 0-7) */
+    const bool one_light = sp.n_lights == 1u;
+    const double em0 = spd_at(table, S, one_light ? sp.light0_em_spd : 0u, lam); /* light 0's emission at this lane's wavelength */
     auto open_sample = [&]() {
         const uint64_t slot = pix_l * sp.batch + s;
         const uint64_t h0 = headers[slot * REC_HEADER_WORDS], h1 = headers[slot * REC_HEADER_WORDS + 1];
@@ -1244,8 +1248,10 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
         term = (uint32_t)(h0 >> 16) & 0xFFu;
         term_spd = (uint32_t)(h0 >> 32) & 0xFFFFu;
         plastic_mask = (uint32_t)(h0 >> 48);
+        vis0 = (uint32_t)(h0 >> 24) & 0xFFu;
         vignette = word_as_double(h1);
         v = 0;
+        vcur = records + (uint64_t)(uint32_t)ph2 * sp.block_words; /* vertex 0 opens the header's first block */
         throughput = 1.0;
         dst = 0.0;
     };
@@ -1261,13 +1267,29 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
             if (is_plastic)
             {
                 /* bdsf() over {bp_diffuse_bdsf, bp_glossy_bdsf}, straight-line (as in the main pass) */
-                const uint64_t *vrec = path_vertex(records, sp.block_words, vw, ph2, ph3, v);
+                const uint64_t *vrec = vcur;
                 const uint64_t w1 = vrec[1];
                 const double dir_pdf = word_as_double(vrec[4]);
                 const double s_a_in = word_as_double(vrec[5]), s_spec = word_as_double(vrec[6]);
                 const uint32_t i_diffuse = (uint32_t)(w1 >> 16) & 0xFFFFu, i_glossy = (uint32_t)(w1 >> 32) & 0xFFFFu;
                 const double diffuse_pi = spd_at(table, S, i_diffuse, lam), glossy = spd_at(table, S, i_glossy, lam);
                 double contribution = 0.0;
+                if (one_light && v < 8u)
+                {
+                    /* one light, and the header says whether it is visible: its three numbers fetched together with the vertex's own
+                     * words (no round trip for a flag word first), its emission row known in advance */
+                    if ((vis0 >> v) & 1u)
+                    {
+                        const uint64_t *lrec = vrec + REC_VERTEX_WORDS;
+                        const double c = word_as_double(lrec[1]), a_in = word_as_double(lrec[2]), spec = word_as_double(lrec[3]);
+                        double reflectance = diffuse_pi * a_in + 0.0;
+                        reflectance = (glossy * spec) * a_in + reflectance;
+                        contribution = contribution + reflectance;
+                        contribution = contribution * em0;
+                        contribution = contribution * c;
+                    }
+                }
+                else
                 for (uint32_t l = 0; l < sp.n_lights; l += 1)
                 {
                     const uint64_t *lrec = vrec + REC_VERTEX_WORDS + l * REC_LIGHT_WORDS;
@@ -1286,6 +1308,7 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
                 reflectance = reflectance * dir_pdf;
                 throughput = throughput * reflectance;
                 v += 1;
+                if (v < n_shaded) vcur = (v & (REC_BLOCK_VERTICES - 1u)) != 0u ? vcur + vw : path_vertex(records, sp.block_words, vw, ph2, ph3, v); /* the next record: the one behind, or a new block */
             }
         }
         else if (n_general > 0)
@@ -1293,7 +1316,7 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
             if (is_general)
             {
                 /* any BDSF list (also plastic vertices beyond the header's 16 flags) */
-                const uint64_t *vrec = path_vertex(records, sp.block_words, vw, ph2, ph3, v);
+                const uint64_t *vrec = vcur;
                 const uint64_t list = vrec[0], w1 = vrec[1], w2 = vrec[2];
                 const double on_dot = word_as_double(vrec[3]), dir_pdf = word_as_double(vrec[4]);
                 const double s_a_in = word_as_double(vrec[5]), s_spec = word_as_double(vrec[6]);
@@ -1324,6 +1347,7 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
                 reflectance = reflectance * dir_pdf;
                 throughput = throughput * reflectance;
                 v += 1;
+                if (v < n_shaded) vcur = (v & (REC_BLOCK_VERTICES - 1u)) != 0u ? vcur + vw : path_vertex(records, sp.block_words, vw, ph2, ph3, v); /* the next record: the one behind, or a new block */
             }
         }
         if (s < sp.n_samples && v >= n_shaded)
