@@ -231,6 +231,9 @@ __global__ __launch_bounds__(PRIMARY_BLOCK) void drt_primary_kernel(DevScene sc,
 /* Bounces: one traversal job per lane and iteration                                                */
 
 #define BOUNCE_BLOCK 256
+#ifndef DRT_BVH_ONE_PER_LEAF
+#define DRT_BVH_ONE_PER_LEAF 1 /* the builder puts one surface in a leaf (BvhBuilder::LEAF): the bounce kernel's leaf step is no loop */
+#endif
 #ifndef DRT_BOUNCE_WAVES_PER_SIMD
 #define DRT_BOUNCE_WAVES_PER_SIMD 3
 #endif
@@ -240,6 +243,15 @@ enum { JOB_NONE = 0, JOB_SHADOW = 1, JOB_CLOSEST = 2 };
 /* One walk of the tree per lane: JOB_CLOSEST finds (min_dist, index) -- minimum distance, lowest surface index on ties, what
  * the reference's linear scan returns (src/daily_ray_trace.c:340-364); JOB_SHADOW answers "any surface nearer than limit?"
  * (:246-268). `stack` is this wave's LDS block, one word per level and lane. */
+/* the next subtree off the lane's stack, or BVH_DONE. (Entries tagged with a lower bound of the subtree's entry distance, so that a
+ * closest-hit walk drops what lies beyond a hit found since the push without fetching the node: 816 ms against 723 on config 5 --
+ * nearer-child-first already leaves little to drop, and the tag's packing and the pop loop cost more.) */
+__device__ __forceinline__ int stack_pop(const int *stack, uint32_t lane, int &sp)
+{
+    if (sp > 0) { sp -= 1; return stack[sp * 64 + lane]; }
+    return BVH_DONE;
+}
+
 __device__ __forceinline__ void bvh_walk(const SceneView &sv, int *stack, uint32_t lane, int job, V3 o, V3 d, double &limit, int &index,
                                          bool &occluded)
 {
@@ -265,8 +277,7 @@ __device__ __forceinline__ void bvh_walk(const SceneView &sv, int *stack, uint32
             }
             else if (hit[0]) cur = ref[0];
             else if (hit[1]) cur = ref[1];
-            else if (sp > 0) { sp -= 1; cur = stack[sp * 64 + lane]; }
-            else cur = BVH_DONE;
+            else cur = stack_pop(stack, lane, sp);
         }
         if (!__any(cur != BVH_DONE)) break;
         while (bvh_is_leaf(cur)) /* leaves, the wave together */
@@ -276,7 +287,14 @@ __device__ __forceinline__ void bvh_walk(const SceneView &sv, int *stack, uint32
             bool stop = false;
             for (int k = 0; k < count; k += 1)
             {
-                const BvhLeafPrim &lp = sv.bvh_leaf[first + k];
+                /* the whole 64-byte record at once: the centre test below wants its last quarter, the intersector (most lanes' next
+                 * step) its first three, and fetched as they are needed that would be three round trips to L2 */
+                const BvhLeafPrim *src = &sv.bvh_leaf[first + k];
+                BvhLeafPrim lp;
+                lp.index = src->index; lp.type = src->type;
+                lp.f[0] = src->f[0]; lp.f[1] = src->f[1]; lp.f[2] = src->f[2]; lp.f[3] = src->f[3];
+                lp.c32[0] = src->c32[0]; lp.c32[1] = src->c32[1]; lp.c32[2] = src->c32[2]; lp.reach32 = src->reach32;
+                __asm__ volatile("" : "+v"(lp.index), "+v"(lp.type), "+v"(lp.f[0]), "+v"(lp.f[1]), "+v"(lp.f[2]), "+v"(lp.f[3]));
                 if (sphere_certainly_missed(lp, r32, lim)) continue;
                 double dist = leaf_distance(sv, lp, o, d);
                 if (job == JOB_CLOSEST)
@@ -289,6 +307,7 @@ __device__ __forceinline__ void bvh_walk(const SceneView &sv, int *stack, uint32
                     }
                 }
                 else if (dist < limit) stop = true; /* the reference breaks at the first occluder; which one does not matter */
+                if (DRT_BVH_ONE_PER_LEAF) break;
             }
             if (stop)
             {
@@ -296,8 +315,7 @@ __device__ __forceinline__ void bvh_walk(const SceneView &sv, int *stack, uint32
                 sp = 0;
                 cur = BVH_DONE;
             }
-            else if (sp > 0) { sp -= 1; cur = stack[sp * 64 + lane]; }
-            else cur = BVH_DONE;
+            else cur = stack_pop(stack, lane, sp);
         }
         if (!__any(cur != BVH_DONE)) break;
     }

@@ -61,8 +61,9 @@ enum
 struct BvhNode
 {
     float   lo[2][3], hi[2][3]; /* the two children's boxes, rounded OUTWARD to f32 (they only prune; tests run in f64) */
-    int32_t child[2];           /* inner child: node index; leaf child: first slot in bvh_leaf */
-    int32_t count[2];           /* 0: inner child, > 0: leaf with that many surfaces, < 0: no child */
+    int32_t child[2];           /* the traversal's reference to the child, ready to use: node index (>= 0), a leaf (bvh_leaf_ref: first
+                                   slot in bvh_leaf and count), or BVH_DONE for no child */
+    int32_t count[2];           /* 0: inner child, > 0: leaf with that many surfaces, < 0: no child (host side and statistics) */
 };                              /* 64 bytes: half a cache line per visit */
 
 /* A surface as the leaves see it: a sphere's four numbers gathered into one 64-byte record, records of a leaf adjacent --
@@ -367,10 +368,9 @@ __device__ __forceinline__ void bvh_children(const BvhNode &n, const Ray32 &r, f
 #pragma unroll
     for (int c = 0; c < 2; c += 1)
     {
-        const int cnt = n.count[c];
+        ref[c] = n.child[c];
         t[c] = bvh_box_entry(n, c, r);
-        hit[c] = cnt >= 0 && t[c] >= 0.0f && t[c] <= limit;
-        ref[c] = cnt > 0 ? bvh_leaf_ref(n.child[c], cnt) : n.child[c];
+        hit[c] = ref[c] != BVH_DONE && t[c] >= 0.0f && t[c] <= limit;
     }
 }
 

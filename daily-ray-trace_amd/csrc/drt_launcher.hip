@@ -183,7 +183,8 @@ struct BvhBuilder
     std::vector<BuildPrim> prims;
     std::vector<BvhNode>   nodes;
     std::vector<uint32_t>  order;
-    int LEAF = 1; /* surfaces per leaf (<= 8: the traversal packs the count in 3 bits). Config 5, trace stage: 757 ms with 1, 855 with 2, 948 with 4 */
+    int LEAF = 1; /* surfaces per leaf (the traversal packs a count <= 8 in 3 bits, but the bounce kernel is built for one: DRT_BVH_ONE_PER_LEAF).
+                     Config 5, trace stage: 757 ms with 1, 855 with 2, 948 with 4 */
     int max_depth = 0;    /* deepest level holding a node: the traversal pushes at most one entry per level */
     double pad32 = 0.0;   /* extra padding of the STORED boxes that pays for testing them in f32 (drt_kernels.h, Ray32) */
     double extent = 0.0;  /* largest |coordinate| of the surfaces' boxes and of the camera */
@@ -217,7 +218,7 @@ struct BvhBuilder
         }
         if (e - b <= (size_t)LEAF)
         {
-            nodes[parent].child[c] = (int32_t)order.size();
+            nodes[parent].child[c] = -2 - ((int32_t)order.size() * 8 + ((int32_t)(e - b) - 1)); /* bvh_leaf_ref(first slot, count) */
             nodes[parent].count[c] = (int32_t)(e - b);
             for (size_t i = b; i < e; i += 1) order.push_back(prims[i].idx);
             return;
@@ -342,7 +343,7 @@ struct BvhBuilder
         pad32 = std::ldexp(extent, -19);
         nodes.push_back(BvhNode());
         nodes[0].count[0] = nodes[0].count[1] = -1;
-        nodes[0].child[0] = nodes[0].child[1] = 0;
+        nodes[0].child[0] = nodes[0].child[1] = BVH_DONE; /* no child */
         if (prims.empty()) return;
         if (prims.size() <= (size_t)LEAF) set_child(0, 0, 0, prims.size(), 0);
         else split(0, 0, prims.size(), 0);
@@ -522,7 +523,6 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene, double r
     if (ctx->use_bvh)
     {
         BvhBuilder bb;
-        if (const char *e = getenv("DRT_BVH_LEAF")) bb.LEAF = std::min(8, std::max(1, atoi(e))); /* tuning knob */
         bb.build(scene, reach);
         /* the traversal stacks hold BVH_STACK entries, one per level at most, and push unchecked */
         if (bb.max_depth > BVH_STACK) return fail(-2, "BVH of %zu surfaces is %d levels deep, the traversal stack holds %d", bb.prims.size(), bb.max_depth, BVH_STACK);
@@ -620,7 +620,6 @@ extern "C" int drt_bvh_stats(const drt_scene *scene, uint32_t *nodes, uint32_t *
     g_last_error.clear();
     if (!scene) return fail(-1, "null argument");
     BvhBuilder bb;
-    if (const char *e = getenv("DRT_BVH_LEAF")) bb.LEAF = std::min(8, std::max(1, atoi(e)));
     bb.build(scene, 0.0);
     if (nodes) *nodes = (uint32_t)bb.nodes.size();
     if (leaf_surfaces) *leaf_surfaces = (uint32_t)bb.order.size();
