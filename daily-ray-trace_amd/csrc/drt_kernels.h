@@ -1186,6 +1186,9 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
 #ifndef SHADE_PREFETCH_DEPTH
 #define SHADE_PREFETCH_DEPTH 2 /* samples whose record loads are in flight ahead of the one being replayed */
 #endif
+#ifndef DRT_SHADE_DEEP_BLOCKS
+#define DRT_SHADE_DEEP_BLOCKS 1 /* plastic runs continue past the prefetched records, a block (four vertices) per load */
+#endif
 #ifndef DRT_SHADE_PLASTIC_RUN
 #define DRT_SHADE_PLASTIC_RUN 1 /* the leading plastic vertices of a path in a loop of their own (one light, one set) */
 #endif
@@ -1288,6 +1291,21 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
                         contribution = contribution * em0;
                         contribution = contribution * c;
                     }
+                }
+                else if (one_light)
+                {
+                    /* later vertices: the flag word says whether the light is visible; it travels WITH the light's three numbers and
+                     * the vertex's own words, and the result is computed either way and then chosen -- behind a branch the loads
+                     * would wait for the flag word's round trip first */
+                    const uint64_t *lrec = vrec + REC_VERTEX_WORDS;
+                    const uint64_t lw0 = lrec[0];
+                    const double c = word_as_double(lrec[1]), a_in = word_as_double(lrec[2]), spec = word_as_double(lrec[3]);
+                    double reflectance = diffuse_pi * a_in + 0.0;
+                    reflectance = (glossy * spec) * a_in + reflectance;
+                    double lit = 0.0 + reflectance;
+                    lit = lit * em0;
+                    lit = lit * c;
+                    contribution = ((uint32_t)(lw0 >> 16) & FLAG_VISIBLE) ? lit : 0.0;
                 }
                 else
                 for (uint32_t l = 0; l < sp.n_lights; l += 1)
@@ -1610,36 +1628,67 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                 run = run < 8u ? run : 8u; /* vis0_mask has 8 bits */
                 if (run != 0u)
                 {
-                    const double *table1 = SPDS_IN_LDS ? (const double *)lds : sc.spds;
-                    const double em0 = spd_at(table1, S, sp.light0_em_spd, lam_c[0]);
-                    for (uint32_t v = 0; v < run; v += 1)
+                const double *table1 = SPDS_IN_LDS ? (const double *)lds : sc.spds;
+                const double em0 = spd_at(table1, S, sp.light0_em_spd, lam_c[0]);
+                /* one vertex of a run: w1 = the record's word 1 (SPD indices), vwords = its words in LDS */
+                auto run_vertex = [&](uint64_t w1, const uint64_t *vwords, bool visible) {
+                    const double diffuse_pi = spd_at(table1, S, (uint32_t)(w1 >> 16) & 0xFFFFu, lam_c[0]);
+                    const double glossy = spd_at(table1, S, (uint32_t)(w1 >> 32) & 0xFFFFu, lam_c[0]);
+                    const double dir_pdf = word_as_double(vwords[4]), s_a_in = word_as_double(vwords[5]), s_spec = word_as_double(vwords[6]);
+                    const double c = word_as_double(vwords[REC_VERTEX_WORDS + 1]), a_in = word_as_double(vwords[REC_VERTEX_WORDS + 2]);
+                    const double spec = word_as_double(vwords[REC_VERTEX_WORDS + 3]);
+                    double contribution = 0.0;
+                    if (visible)
                     {
-                        const uint32_t idx = (v * vw + 1u) & 63u;
-                        const uint64_t wa = readlane64(cur[0], idx);
-                        const uint64_t wb = readlane64(cur[SHADE_PREFETCH_REGS > 1 ? 1 : 0], idx);
-                        const uint64_t w1 = (v < vpr) ? wa : wb;
-                        const double diffuse_pi = spd_at(table1, S, (uint32_t)(w1 >> 16) & 0xFFFFu, lam_c[0]);
-                        const double glossy = spd_at(table1, S, (uint32_t)(w1 >> 32) & 0xFFFFu, lam_c[0]);
-                        const uint64_t *vwords = rec_words + v * vw;
-                        const double dir_pdf = word_as_double(vwords[4]), s_a_in = word_as_double(vwords[5]), s_spec = word_as_double(vwords[6]);
-                        const double c = word_as_double(vwords[REC_VERTEX_WORDS + 1]), a_in = word_as_double(vwords[REC_VERTEX_WORDS + 2]);
-                        const double spec = word_as_double(vwords[REC_VERTEX_WORDS + 3]);
-                        double contribution = 0.0;
-                        if ((vis0_mask >> v) & 1u)
-                        {
-                            double reflectance = diffuse_pi * a_in + 0.0;
-                            reflectance = (glossy * spec) * a_in + reflectance;
-                            contribution = contribution + reflectance; /* :323 */
-                            contribution = contribution * em0;         /* :324 */
-                            contribution = contribution * c;           /* :326-327 */
-                        }
-                        dst[0] = dst[0] + throughput[0] * contribution; /* :461-462 */
-                        double reflectance = diffuse_pi * s_a_in + 0.0;
-                        reflectance = (glossy * s_spec) * s_a_in + reflectance;
-                        reflectance = reflectance * dir_pdf;         /* :468 */
-                        throughput[0] = throughput[0] * reflectance; /* :469 */
+                        double reflectance = diffuse_pi * a_in + 0.0;
+                        reflectance = (glossy * spec) * a_in + reflectance;
+                        contribution = contribution + reflectance; /* :323 */
+                        contribution = contribution * em0;         /* :324 */
+                        contribution = contribution * c;           /* :326-327 */
                     }
-                    v_first = run;
+                    dst[0] = dst[0] + throughput[0] * contribution; /* :461-462 */
+                    double reflectance = diffuse_pi * s_a_in + 0.0;
+                    reflectance = (glossy * s_spec) * s_a_in + reflectance;
+                    reflectance = reflectance * dir_pdf;         /* :468 */
+                    throughput[0] = throughput[0] * reflectance; /* :469 */
+                };
+                for (uint32_t v = 0; v < run; v += 1)
+                {
+                    const uint32_t idx = (v * vw + 1u) & 63u;
+                    const uint64_t wa = readlane64(cur[0], idx);
+                    const uint64_t wb = readlane64(cur[SHADE_PREFETCH_REGS > 1 ? 1 : 0], idx);
+                    run_vertex((v < vpr) ? wa : wb, rec_words + v * vw, ((vis0_mask >> v) & 1u) != 0u);
+                }
+                v_first = run;
+#if DRT_SHADE_DEEP_BLOCKS
+                /* Beyond the prefetched records (vertices 8 and up: long paths in closed scenes), when everything so far was a run: the
+                 * path's further blocks one at a time -- four vertices by ONE coalesced load, which takes the place of vertices 0-3
+                 * in this sample's LDS slot, then the same loop (visibility from the light's flag word, the header has 8 bits). A
+                 * round trip per block instead of one per vertex, and none of the general loop's work. */
+                if (run == 2u * REC_BLOCK_VERTICES && n_shaded > run && vw * REC_BLOCK_VERTICES == 64u)
+                {
+                    const uint64_t h3s = readlane64(h3, s);
+                    for (uint32_t b = 2u; b * REC_BLOCK_VERTICES < n_shaded && b < 4u; b += 1) /* plastic_mask covers 16 vertices */
+                    {
+                        uint32_t id = (uint32_t)h3s;
+                        if (b >= REC_HEADER_BLOCKS) id = ((const uint32_t *)(records + (uint64_t)(uint32_t)(h3s >> 32) * sp.block_words))[b - REC_HEADER_BLOCKS];
+                        const uint64_t blockw = records[(uint64_t)id * sp.block_words + lane];
+                        uint64_t *slot = rec_lds + (s & 1u) * (64u * SHADE_PREFETCH_REGS);
+                        slot[lane] = blockw;
+                        const uint32_t v_lo = b * REC_BLOCK_VERTICES;
+                        const uint32_t v_hi = n_shaded < v_lo + REC_BLOCK_VERTICES ? n_shaded : v_lo + REC_BLOCK_VERTICES;
+                        uint32_t v = v_lo;
+                        for (; v < v_hi && ((plastic_mask >> v) & 1u); v += 1)
+                        {
+                            const uint32_t w0 = (v - v_lo) * vw;
+                            const uint64_t lw0 = readlane64(blockw, w0 + REC_VERTEX_WORDS);
+                            run_vertex(readlane64(blockw, w0 + 1u), slot + w0, ((uint32_t)(lw0 >> 16) & FLAG_VISIBLE) != 0u);
+                        }
+                        v_first = v;
+                        if (v < v_hi) break; /* something else than plastic: the general loop takes over */
+                    }
+                }
+#endif
                 }
             }
 #endif
