@@ -1220,9 +1220,6 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
     const bool act = g < (uint32_t)(chunk_end - chunk_base) && g < 64u / R;
     const uint32_t lam = sp.tail_first + j; /* < S by construction */
     const double *table = SPDS_IN_LDS ? (const double *)lds : sc.spds;
-    double *px = film_pixels + pix_l * (uint64_t)(XYZ ? XYZ_FILM_WORDS : S + 1);
-    double *pa = XYZ ? nullptr : film_avgs + pix_l * (uint64_t)S;
-    double *pv = XYZ ? nullptr : film_vars + pix_l * (uint64_t)S;
     /*
      * Phase A -- radiance, paced per pixel. If the 12 pixels stepped through their samples together, every sample
      * would cost the longest of 12 paths (about 4.5 vertices where the average is 1.65), and every vertex step both
@@ -1233,13 +1230,12 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
      * tail_stage). The wave runs for the pixel with the most vertices in the batch, and the general code only runs
      * when it is what most lanes need.
      */
-    double *stage = sp.tail_stage + (pix_l * (uint64_t)sp.batch) * R + j;
     uint32_t s = act ? 0u : sp.n_samples; /* lanes without a pixel are done from the start */
-    uint32_t v = 0, n_shaded = 0, term = 0, term_spd = 0, plastic_mask = 0;
+    uint32_t v = 0, n_shaded = 0;
+    uint64_t ph0 = 0; /* the header's first word: vertex count, how the path ended, flags (fields taken out where they are used) */
     double vignette = 0.0, throughput = 1.0, dst = 0.0;
     uint64_t ph2 = 0, ph3 = 0; /* the path's block words */
     const uint64_t *vcur = records; /* the record of vertex v */
-    uint32_t vis0 = 0;          /* the header's "light 0 visible" bits (vertices 0-7) */
     const bool one_light = sp.n_lights == 1u;
     const double em0 = spd_at(table, S, one_light ? sp.light0_em_spd : 0u, lam); /* light 0's emission at this lane's wavelength */
     auto open_sample = [&]() {
@@ -1247,11 +1243,8 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
         const uint64_t h0 = headers[slot * REC_HEADER_WORDS], h1 = headers[slot * REC_HEADER_WORDS + 1];
         ph2 = headers[slot * REC_HEADER_WORDS + 2];
         ph3 = headers[slot * REC_HEADER_WORDS + 3];
+        ph0 = h0;
         n_shaded = (uint32_t)(h0 & 0xFFFFu);
-        term = (uint32_t)(h0 >> 16) & 0xFFu;
-        term_spd = (uint32_t)(h0 >> 32) & 0xFFFFu;
-        plastic_mask = (uint32_t)(h0 >> 48);
-        vis0 = (uint32_t)(h0 >> 24) & 0xFFu;
         vignette = word_as_double(h1);
         v = 0;
         vcur = records + (uint64_t)(uint32_t)ph2 * sp.block_words; /* vertex 0 opens the header's first block */
@@ -1262,7 +1255,7 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
     while (__any(s < sp.n_samples))
     {
         const bool has_vertex = s < sp.n_samples && v < n_shaded;
-        const bool is_plastic = has_vertex && v < 16u && ((plastic_mask >> v) & 1u);
+        const bool is_plastic = has_vertex && v < 16u && (((uint32_t)(ph0 >> 48) >> v) & 1u); /* bits 48-63: two-lobe plastic */
         const bool is_general = has_vertex && !is_plastic;
         const uint32_t n_plastic = (uint32_t)__popcll(__ballot(is_plastic)), n_general = (uint32_t)__popcll(__ballot(is_general));
         if (n_plastic > 0 && n_plastic >= n_general)
@@ -1281,7 +1274,7 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
                 {
                     /* one light, and the header says whether it is visible: its three numbers fetched together with the vertex's own
                      * words (no round trip for a flag word first), its emission row known in advance */
-                    if ((vis0 >> v) & 1u)
+                    if (((uint32_t)(ph0 >> 24) >> v) & 1u) /* bits 24-31: light 0 visible */
                     {
                         const uint64_t *lrec = vrec + REC_VERTEX_WORDS;
                         const double c = word_as_double(lrec[1]), a_in = word_as_double(lrec[2]), spec = word_as_double(lrec[3]);
@@ -1371,12 +1364,16 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
         if (s < sp.n_samples && v >= n_shaded)
         {
             /* the path's last vertex is done (or it had none): close the sample, :452-457 and :615 */
-            if (term == 1) dst = dst + throughput * spd_at(table, S, term_spd, lam);
-            stage[(uint64_t)s * R] = dst * vignette;
+            if (((uint32_t)(ph0 >> 16) & 0xFFu) == 1u) dst = dst + throughput * spd_at(table, S, (uint32_t)(ph0 >> 32) & 0xFFFFu, lam);
+            sp.tail_stage[((chunk_base + g) * (uint64_t)sp.batch + s) * R + j] = dst * vignette; /* the address from scratch: a pointer kept live costs two registers */
             s += 1;
             if (s < sp.n_samples) open_sample();
         }
     }
+    double *px = film_pixels + pix_l * (uint64_t)(XYZ ? XYZ_FILM_WORDS : S + 1);
+    double *pa = XYZ ? nullptr : film_avgs + pix_l * (uint64_t)S;
+    double *pv = XYZ ? nullptr : film_vars + pix_l * (uint64_t)S;
+    const double *stage = sp.tail_stage + (pix_l * (uint64_t)sp.batch) * R + j;
     /* Phase B -- the film update (src/daily_ray_trace.c:732-743), the pixels' samples in order, all pixels in step */
     double f_sum = (act && !XYZ) ? px[lam] : 0.0, f_avg = (act && !XYZ) ? pa[lam] : 0.0, f_var = (act && !XYZ) ? pv[lam] : 0.0;
 #pragma unroll 4
@@ -1549,6 +1546,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
          * number per register, from the header (scalar), and consecutive lanes read consecutive words. Only the header's own
          * blocks are prefetched; deeper vertices are fetched when they are replayed. */
         auto prefetch = [&](uint32_t sa, uint32_t nw, uint64_t *dst) {
+            if (nw == 0u) return; /* three paths in five have no shaded vertex: nothing to fetch, and what the registers hold is never read */
             const uint64_t b2 = readlane64(h2, sa);
 #pragma unroll
             for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1)
