@@ -1531,7 +1531,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
         /* the pixel's samples in windows of 64: the headers of a window arrive in one coalesced load, lane s <- sample s */
       for (uint32_t s0 = 0; s0 < sp.n_samples; s0 += 64u)
       {
-        const uint32_t n_win = (sp.n_samples - s0 < 64u) ? sp.n_samples - s0 : 64u;
+        const uint32_t n_win = (uint32_t)__builtin_amdgcn_readfirstlane((int)((sp.n_samples - s0 < 64u) ? sp.n_samples - s0 : 64u)); /* 1..64, and in a scalar register: the loop's end test is then scalar too */
+        __builtin_assume(n_win >= 1u);
         uint64_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
         if (lane < n_win)
         {
