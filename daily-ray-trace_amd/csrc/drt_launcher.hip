@@ -516,8 +516,7 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene, double r
     ctx->trace_lds = trace_lds_bytes(n_surf, n_lights, scene->num_materials);
     /* small scenes: whole scan out of LDS; large scenes: tables stay in HBM/L2 and a BVH prunes the scan */
     ctx->scene_in_lds = ctx->trace_lds <= 64 * 1024 && n_surf <= 96 && !getenv("DRT_FORCE_BVH");
-    if (getenv("DRT_NO_BVH")) ctx->use_bvh = false; /* tuning knob: brute-force scan from HBM */
-    else ctx->use_bvh = !ctx->scene_in_lds;
+    ctx->use_bvh = !ctx->scene_in_lds; /* (round 1's brute-force scan from HBM, DRT_NO_BVH, is gone: the two BVH kernels are the only path for such scenes) */
     d.bvh_nodes = nullptr;
     d.bvh_leaf = nullptr;
     if (ctx->use_bvh)
