@@ -374,125 +374,12 @@ __device__ __forceinline__ void bvh_children(const BvhNode &n, const Ray32 &r, f
     }
 }
 
-/* closest hit through the hierarchy: min distance, lowest index on ties */
-__device__ __forceinline__ void bvh_closest(const SceneView &sv, V3 o, V3 d, double &min_dist, int &index)
-{
-    const Ray32 r32 = bvh_ray32(o, d);
-    float lim = bvh_limit32(min_dist);
-    int   stack[BVH_STACK];
-    float stack_t[BVH_STACK]; /* lower bound of the entry distance of the pushed subtree: a later, nearer hit culls it on pop */
-    int sp = 0;
-    int cur = 0;
-    for (;;)
-    {
-        while (cur >= 0) /* inner nodes */
-        {
-            const BvhNode &n = sv.bvh_nodes[cur];
-            int ref[2];
-            float t[2];
-            bool hit[2];
-            bvh_children(n, r32, lim, ref, t, hit);
-            if (hit[0] && hit[1])
-            {
-                const int near = t[1] < t[0] ? 1 : 0; /* nearer box first */
-                stack[sp] = ref[1 - near]; /* sp < BVH_STACK: the builder refuses deeper trees (build_device_scene) */
-                stack_t[sp] = t[1 - near];
-                sp += 1;
-                cur = ref[near];
-            }
-            else if (hit[0]) cur = ref[0];
-            else if (hit[1]) cur = ref[1];
-            else
-            {
-                cur = BVH_DONE;
-                while (sp > 0)
-                {
-                    sp -= 1;
-                    if (!(stack_t[sp] > lim))
-                    {
-                        cur = stack[sp];
-                        break;
-                    }
-                }
-            }
-        }
-        if (cur == BVH_DONE) break;
-        while (bvh_is_leaf(cur)) /* leaves */
-        {
-            const int packed = -2 - cur;
-            const int first = packed >> 3, count = (packed & 7) + 1;
-            for (int k = 0; k < count; k += 1)
-            {
-                const BvhLeafPrim &lp = sv.bvh_leaf[first + k];
-                double dist = leaf_distance(sv, lp, o, d);
-                if (dist < min_dist || (dist == min_dist && (int)lp.index < index))
-                {
-                    min_dist = dist;
-                    index = (int)lp.index;
-                    lim = bvh_limit32(min_dist);
-                }
-            }
-            cur = BVH_DONE;
-            while (sp > 0)
-            {
-                sp -= 1;
-                if (!(stack_t[sp] > lim))
-                {
-                    cur = stack[sp];
-                    break;
-                }
-            }
-        }
-        if (cur == BVH_DONE) break;
-    }
-}
-
-/* any surface nearer than vis_dist? (the shadow test; order does not matter for a yes/no answer) */
-__device__ __forceinline__ bool bvh_occluded(const SceneView &sv, V3 o, V3 d, double vis_dist)
-{
-    const Ray32 r32 = bvh_ray32(o, d);
-    const float lim = bvh_limit32(vis_dist);
-    int stack[BVH_STACK];
-    int sp = 0;
-    int cur = 0;
-    for (;;)
-    {
-        while (cur >= 0)
-        {
-            const BvhNode &n = sv.bvh_nodes[cur];
-            int ref[2];
-            float t[2];
-            bool hit[2];
-            bvh_children(n, r32, lim, ref, t, hit);
-            if (hit[0] && hit[1])
-            {
-                stack[sp++] = ref[1];
-                cur = ref[0];
-            }
-            else if (hit[0]) cur = ref[0];
-            else if (hit[1]) cur = ref[1];
-            else cur = sp > 0 ? stack[--sp] : BVH_DONE;
-        }
-        if (cur == BVH_DONE) return false;
-        while (bvh_is_leaf(cur))
-        {
-            const int packed = -2 - cur;
-            const int first = packed >> 3, count = (packed & 7) + 1;
-            for (int k = 0; k < count; k += 1)
-                if (leaf_distance(sv, sv.bvh_leaf[first + k], o, d) < vis_dist) return true;
-            cur = sp > 0 ? stack[--sp] : BVH_DONE;
-        }
-        if (cur == BVH_DONE) return false;
-    }
-}
-
 /* points_mutually_visible, src/daily_ray_trace.c:238-270 */
 __device__ __forceinline__ bool points_mutually_visible(const SceneView &sv, V3 p0, V3 p1)
 {
     V3 dir = v_normalise(v_sub(p1, p0));
     V3 o = v_sum(p0, v_mul(dir, DRT_VIS_FUDGE));
     double vis_dist = v_length(v_sub(p1, o)) - DRT_VIS_FUDGE;
-    if (sv.bvh_nodes) return !bvh_occluded(sv, o, dir, vis_dist);
     bool visible = true;
     for (uint32_t i = 0; i < sv.n_surf; i += 1)
     {
@@ -519,8 +406,6 @@ __device__ __forceinline__ void find_ray_intersection(const SceneView &sv, const
     double min_dist = DRT_INF;
     int index = -1;
     ro = v_sum(ro, v_mul(rd, DRT_VIS_FUDGE));
-    if (sv.bvh_nodes) bvh_closest(sv, ro, rd, min_dist, index);
-    else
     {
         for (uint32_t i = 0; i < sv.n_surf; i += 1)
         {
