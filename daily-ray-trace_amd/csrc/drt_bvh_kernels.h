@@ -231,6 +231,9 @@ __global__ __launch_bounds__(PRIMARY_BLOCK) void drt_primary_kernel(DevScene sc,
 /* Bounces: one traversal job per lane and iteration                                                */
 
 #define BOUNCE_BLOCK 256
+#ifndef DRT_BOUNCE_IN_STEP
+#define DRT_BOUNCE_IN_STEP 1
+#endif
 #ifndef DRT_BVH_ONE_PER_LEAF
 #define DRT_BVH_ONE_PER_LEAF 1 /* the builder puts one surface in a leaf (BvhBuilder::LEAF): the bounce kernel's leaf step is no loop */
 #endif
@@ -359,11 +362,25 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
     ip.surface_mat = ip.incident_mat = ip.transmit_mat = 0;
     ip.index = -1;
 
+    /* A path at a vertex takes one iteration per light (the shadow job) and one more for its next ray (the closest-hit job), so a
+     * wave whose lanes all started together stays IN STEP -- every lane on the same kind of job -- as long as new paths only join
+     * at the start of that cycle. Then an iteration runs the sections of ONE kind of job with every live lane in them and skips the
+     * others (their branches see no lane), instead of all of them half empty; a lane whose path ends waits for the cycle's start,
+     * at most one iteration with one light. */
+#if DRT_BOUNCE_IN_STEP
+    const uint32_t cycle = sv.n_lights + 1u;
+    uint32_t phase = 0;
+#endif
     for (;;)
     {
         /* ---- refill idle lanes from the queue of paths whose first vertex is known ---- */
         unsigned long long idle_mask = __ballot(!alive);
+#if DRT_BOUNCE_IN_STEP
+        if (!exhausted && idle_mask == ~0ull) phase = 0; /* nobody left to stay in step with */
+        if (idle_mask != 0ull && !exhausted && phase == 0u)
+#else
         if (idle_mask != 0ull && !exhausted)
+#endif
         {
             const uint32_t want = (uint32_t)__popcll(idle_mask);
             const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
@@ -421,6 +438,9 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
             }
         }
         if (!__any(alive)) break;
+#if DRT_BOUNCE_IN_STEP
+        phase = phase + 1u == cycle ? 0u : phase + 1u;
+#endif
         /* a spare record block for the lanes whose path may open one at its next vertex (the whole wave takes part) */
         if (!path_spare_block(tp, wp, alive, shaded, spare, spare_tbl, lane))
         {
