@@ -62,7 +62,7 @@ struct drt_context
     uint64_t  pool_blocks = 0;          /* blocks in d_records */
     uint32_t  worst_blocks_per_path = 0; /* what a path of max_depth vertices takes (table block included) */
     double    est_blocks_per_path = 0.0; /* measured on a sample of the tile when the context is created */
-    struct Batch { uint32_t first_sample, n_samples; uint64_t seq; };
+    struct Batch { uint32_t first_sample, n_samples; uint64_t seq; uint32_t row0, rows; }; /* rows == 0: the whole tile */
     std::vector<Batch> inflight;         /* kernel pairs enqueued since the last synchronisation (redone if the pool ran out) */
     uint64_t  next_seq = 1;
     uint64_t  redone_batches = 0, pool_peak = 0;
@@ -551,21 +551,21 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene, double r
 }
 
 template <int NSETS, bool XYZ>
-static int launch_shade_mode(drt_context *ctx, uint32_t grid, const ShadeParams &sp)
+static int launch_shade_mode(drt_context *ctx, uint32_t grid, const ShadeParams &sp, double *const film[3])
 {
     if (ctx->spds_in_lds)
         hipLaunchKernelGGL((drt_shade_kernel<NSETS, true, XYZ>), dim3(grid), dim3(SHADE_BLOCK), ctx->shade_lds, ctx->stream, ctx->dsc, sp,
-                           ctx->d_records, ctx->d_headers, ctx->d_pixels, ctx->d_avgs, ctx->d_vars, ctx->d_counters + DRT_NUM_COUNTERS + 1);
+                           ctx->d_records, ctx->d_headers, film[0], film[1], film[2], ctx->d_counters + DRT_NUM_COUNTERS + 1);
     else
         hipLaunchKernelGGL((drt_shade_kernel<NSETS, false, XYZ>), dim3(grid), dim3(SHADE_BLOCK), ctx->shade_lds, ctx->stream, ctx->dsc, sp,
-                           ctx->d_records, ctx->d_headers, ctx->d_pixels, ctx->d_avgs, ctx->d_vars, ctx->d_counters + DRT_NUM_COUNTERS + 1);
+                           ctx->d_records, ctx->d_headers, film[0], film[1], film[2], ctx->d_counters + DRT_NUM_COUNTERS + 1);
     return 0;
 }
 
 template <int NSETS>
-static int launch_shade_sets(drt_context *ctx, uint32_t grid, const ShadeParams &sp)
+static int launch_shade_sets(drt_context *ctx, uint32_t grid, const ShadeParams &sp, double *const film[3])
 {
-    return ctx->xyz_mode ? launch_shade_mode<NSETS, true>(ctx, grid, sp) : launch_shade_mode<NSETS, false>(ctx, grid, sp);
+    return ctx->xyz_mode ? launch_shade_mode<NSETS, true>(ctx, grid, sp, film) : launch_shade_mode<NSETS, false>(ctx, grid, sp, film);
 }
 
 /* How the S wavelengths map to lanes: n full 64-lane sets, plus (when the remainder is small) a packed tail pass */
@@ -584,14 +584,15 @@ static void shade_sets(uint32_t S, uint32_t *n_sets, uint32_t *tail_first, uint3
     else *n_sets = full + 1;
 }
 
-static int launch_shade(drt_context *ctx, uint32_t grid, const ShadeParams &sp)
+/* film: the three buffers from the first pixel the launch covers on (a launch may cover a range of the tile's rows) */
+static int launch_shade(drt_context *ctx, uint32_t grid, const ShadeParams &sp, double *const film[3])
 {
     switch (ctx->shade_sets)
     {
-        case 1: return launch_shade_sets<1>(ctx, grid, sp);
-        case 2: return launch_shade_sets<2>(ctx, grid, sp);
-        case 3: return launch_shade_sets<3>(ctx, grid, sp);
-        default: return launch_shade_sets<4>(ctx, grid, sp);
+        case 1: return launch_shade_sets<1>(ctx, grid, sp, film);
+        case 2: return launch_shade_sets<2>(ctx, grid, sp, film);
+        case 3: return launch_shade_sets<3>(ctx, grid, sp, film);
+        default: return launch_shade_sets<4>(ctx, grid, sp, film);
     }
 }
 
@@ -641,7 +642,7 @@ static size_t pixels_bytes(const drt_context *ctx)
     return (size_t)ctx->n_pix * (ctx->xyz_mode ? (size_t)XYZ_FILM_WORDS : (size_t)ctx->dsc.S + 1) * 8;
 }
 
-static int enqueue_trace(drt_context *ctx, uint32_t first_sample, uint32_t n, uint32_t hits_sample_offset);
+static int enqueue_trace(drt_context *ctx, uint32_t first_sample, uint32_t n, uint32_t hits_sample_offset, uint32_t row0 = 0, uint32_t rows = 0, uint32_t stride = 0);
 
 /* waves of the trace-stage kernel that takes record blocks, for a launch of n_paths */
 static uint64_t trace_waves(const drt_context *ctx, uint64_t n_paths)
@@ -949,7 +950,6 @@ extern "C" int drt_set_stream(drt_context *ctx, void *hip_stream)
 }
 
 extern "C" int drt_synchronize(drt_context *ctx);
-static int enqueue_trace(drt_context *ctx, uint32_t first_sample, uint32_t n, uint32_t hits_sample_offset);
 
 static int next_events(drt_context *ctx, hipEvent_t out[3])
 {
@@ -989,24 +989,28 @@ __global__ void drt_mark_pair_kernel(unsigned long long *state, unsigned long lo
 
 /* The trace stage of one kernel pair over samples [first_sample, first_sample + n) of every tile pixel: work queues and the
  * pool cursor reset, then drt_trace_kernel (scene in LDS) or drt_primary_kernel + drt_bounce_kernel (scene behind the hierarchy). */
-static int enqueue_trace(drt_context *ctx, uint32_t first_sample, uint32_t n, uint32_t hits_sample_offset)
+static int enqueue_trace(drt_context *ctx, uint32_t first_sample, uint32_t n, uint32_t hits_sample_offset, uint32_t row0, uint32_t rows, uint32_t stride)
 {
     const drt_params &p = ctx->params;
     TraceParams tp{};
-    tp.width = p.width; tp.height = p.height; tp.x0 = p.x0; tp.y0 = p.y0;
-    tp.tile_w = p.tile_w; tp.tile_h = p.tile_h; tp.row_stride = p.row_stride;
+    /* rows [row0, row0 + rows) of the tile (rows == 0: all of it): the kernels see a tile that starts there; headers, records and the
+     * staging buffers are indexed from the launch's first pixel */
+    const bool whole = rows == 0;
+    if (whole) { row0 = 0; rows = p.tile_h; }
+    tp.width = p.width; tp.height = p.height; tp.x0 = p.x0; tp.y0 = p.y0 + row0 * p.row_stride;
+    tp.tile_w = p.tile_w; tp.tile_h = rows; tp.row_stride = p.row_stride;
     tp.first_sample = first_sample;
     tp.n_samples = n;
     tp.max_depth = p.max_depth;
     tp.pixel_scheme = p.pixel_scheme;
     tp.record_hits = (p.flags & DRT_FLAG_RECORD_HITS) ? 1u : 0u;
     tp.seed = p.seed;
-    tp.n_pix = ctx->n_pix;
-    tp.n_paths = ctx->n_pix * n;
+    tp.n_pix = whole ? ctx->n_pix : (uint64_t)rows * p.tile_w;
+    tp.n_paths = tp.n_pix * n;
     tp.vertex_words = ctx->vertex_words;
     tp.block_words = ctx->block_words;
     tp.hits_sample_offset = hits_sample_offset;
-    tp.batch = ctx->batch_spp;
+    tp.batch = stride ? stride : ctx->batch_spp; /* sample slots per pixel in the header array (a launch over fewer rows may take more samples) */
     tp.pool_blocks = (uint32_t)ctx->pool_blocks;
     unsigned long long *work = ctx->d_counters + DRT_NUM_COUNTERS;
     tp.pool_cursor = work + 4;
@@ -1041,18 +1045,20 @@ static int enqueue_trace(drt_context *ctx, uint32_t first_sample, uint32_t n, ui
 }
 
 /* One kernel pair: trace, shade + film, and the mark that tells the host whether the pair was complete. */
-static int enqueue_pair(drt_context *ctx, uint32_t first_sample, uint32_t n, uint32_t hits_sample_offset)
+static int enqueue_pair(drt_context *ctx, uint32_t first_sample, uint32_t n, uint32_t hits_sample_offset, uint32_t row0 = 0, uint32_t rows = 0, uint32_t stride = 0)
 {
     hipEvent_t ev[3];
     int rc = next_events(ctx, ev);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ev[0], ctx->stream));
-    if ((rc = enqueue_trace(ctx, first_sample, n, hits_sample_offset))) return rc;
+    if ((rc = enqueue_trace(ctx, first_sample, n, hits_sample_offset, row0, rows, stride))) return rc;
+    const uint64_t n_pix = rows ? (uint64_t)rows * ctx->params.tile_w : ctx->n_pix; /* pixels of this launch */
+    const uint64_t pix0 = rows ? (uint64_t)row0 * ctx->params.tile_w : 0;           /* its first pixel in the tile */
     HIP_TRY(hipEventRecord(ev[1], ctx->stream));
 
     unsigned long long *work = ctx->d_counters + DRT_NUM_COUNTERS;
     ShadeParams sp{};
-    sp.n_pix = ctx->n_pix;
+    sp.n_pix = n_pix;
     sp.n_samples = n;
     sp.first_sample = first_sample;
     sp.vertex_words = ctx->vertex_words;
@@ -1060,14 +1066,14 @@ static int enqueue_pair(drt_context *ctx, uint32_t first_sample, uint32_t n, uin
     sp.block_words = ctx->block_words;
     sp.overflow = (const uint32_t *)(work + 5);
     sp.n_lights = ctx->dsc.n_lights;
-    sp.batch = ctx->batch_spp;
+    sp.batch = stride ? stride : ctx->batch_spp;
     sp.tail_first = ctx->tail_first;
     sp.tail_count = ctx->tail_count;
     sp.tail_stage = ctx->d_tail_stage;
     sp.light0_em_spd = ctx->light0_em_spd;
     sp.cmf_rw = ctx->cmf_rw; sp.cmf_x = ctx->cmf_x; sp.cmf_y = ctx->cmf_y; sp.cmf_z = ctx->cmf_z;
     sp.chunk = ctx->tail_count ? 64u / ctx->tail_count : SHADE_PIXEL_CHUNK;
-    uint64_t groups = (ctx->n_pix + sp.chunk - 1) / sp.chunk;
+    uint64_t groups = (n_pix + sp.chunk - 1) / sp.chunk;
     const bool inline_tail = ctx->tail_count != 0;
     /* work items: a group's main pass in pieces of sub_pixels pixels (+ its tail pass as an item of its own) when the
      * groups alone are too few to keep the last round of the persistent waves short */
@@ -1078,7 +1084,7 @@ static int enqueue_pair(drt_context *ctx, uint32_t first_sample, uint32_t n, uin
         {
             /* pixels per main-pass item: small enough for >= 64 items per wave (short last round), large enough for
              * >= 256 paths per item (the queue is one atomic counter) */
-            uint64_t p_balance = ctx->n_pix / (waves * 64);
+            uint64_t p_balance = n_pix / (waves * 64);
             uint64_t p_atomic = (256 + n - 1) / n;
             uint32_t P = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(std::max(p_balance, p_atomic), 1), sp.chunk);
             subs = (sp.chunk + P - 1) / P;
@@ -1107,14 +1113,17 @@ static int enqueue_pair(drt_context *ctx, uint32_t first_sample, uint32_t n, uin
         }
     }
     uint32_t sgrid = (uint32_t)std::min<uint64_t>(((uint64_t)sp.n_items + SHADE_WAVES - 1) / SHADE_WAVES, (uint64_t)ctx->shade_grid_cap);
-    rc = launch_shade(ctx, sgrid, sp);
+    const size_t S_ = ctx->dsc.S;
+    double *const film[3] = {ctx->d_pixels + pix0 * (ctx->xyz_mode ? (size_t)XYZ_FILM_WORDS : S_ + 1),
+                             ctx->d_avgs ? ctx->d_avgs + pix0 * S_ : nullptr, ctx->d_vars ? ctx->d_vars + pix0 * S_ : nullptr};
+    rc = launch_shade(ctx, sgrid, sp, film);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     const uint64_t seq = ctx->next_seq++;
     hipLaunchKernelGGL(drt_mark_pair_kernel, dim3(1), dim3(1), 0, ctx->stream, work + 4, (unsigned long long)seq);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[2], ctx->stream));
-    ctx->inflight.push_back({first_sample, n, seq});
+    ctx->inflight.push_back({first_sample, n, seq, row0, rows});
     return 0;
 }
 
@@ -1137,7 +1146,7 @@ static int redo_batches(drt_context *ctx, uint64_t last_good_seq)
         {
             /* (hit logging, when on, is indexed by sample offset within the caller's drt_render call: the offsets of a redone
              *  batch are not known here, and parity tests that log hits never run with an undersized pool) */
-            int rc = enqueue_pair(ctx, b.first_sample + done, std::min(safe, b.n_samples - done), done);
+            int rc = enqueue_pair(ctx, b.first_sample + done, std::min(safe, b.n_samples - done), done, b.row0, b.rows);
             if (rc) return rc;
         }
     }
@@ -1358,7 +1367,43 @@ extern "C" int drt_render_tile(const drt_scene *scene, const drt_camera *camera,
         /* accumulate INTO the caller's buffers: start from their contents (unless the caller vouches they are zero) */
         if (!(params->flags & DRT_FLAG_FILM_ZERO) && (rc = drt_write_film(ctx, dst_pixels, dst_avgs, dst_vars))) break;
         t[2] = wall_ms();
-        if ((rc = drt_render(ctx, params->first_sample, params->spp))) break;
+        /* The tile goes out in row blocks, each with all its samples (as many per kernel pair as the record pool was sized for: a
+         * quarter of the rows takes four times the samples), so that a block's film rows cross PCIe while the next block renders:
+         * what is left exposed of the 1.7 GB download is its last quarter. (A pool that runs out on the way: drt_synchronize
+         * renders again from there, and the film is fetched whole.) */
+        const uint32_t B = ctx->batch_spp;
+        uint32_t n_blocks = 8; /* 1024^2 x 256 spp, wall: 226 ms in one piece, 219 / 214 / 206 ms in 2 / 4 / 8 blocks (kernels 187 -> 197 ms: smaller launches) */
+        if (getenv("DRT_ONESHOT_BLOCKS")) n_blocks = (uint32_t)std::max(1, atoi(getenv("DRT_ONESHOT_BLOCKS")));
+        const uint32_t per = (ctx->params.tile_h + n_blocks - 1) / n_blocks; /* rows per block */
+        const bool blocks_ok = params->spp != 0 && n_blocks > 1 && !(params->flags & DRT_FLAG_RECORD_HITS) && ctx->params.tile_h >= 16 * n_blocks &&
+                               (uint64_t)ctx->params.tile_w * ctx->params.tile_h >= (1u << 18);
+        std::vector<hipEvent_t> block_done;
+        if (!blocks_ok)
+        {
+            if ((rc = drt_render(ctx, params->first_sample, params->spp))) break;
+        }
+        else
+        {
+            /* samples per pair: five eighths of the paths of a full-tile pair over this block's pixels -- the pool is sized from the
+             * tile's AVERAGE path, and some rows of an image (the ones with the objects in them) run well above it */
+            const uint32_t n_blk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(params->spp, 4096), ctx->n_pix * (uint64_t)B * 5 / 8 / ((uint64_t)per * ctx->params.tile_w)));
+            for (uint32_t r0 = 0; r0 < ctx->params.tile_h && !rc; r0 += per)
+            {
+                const uint32_t rows = std::min(per, ctx->params.tile_h - r0);
+                for (uint32_t done = 0; done < params->spp && !rc; done += n_blk)
+                {
+                    const uint32_t n = std::min(n_blk, params->spp - done);
+                    rc = enqueue_pair(ctx, params->first_sample + done, n, 0, r0, rows, n);
+                }
+                hipEvent_t e;
+                if (!rc && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess)
+                {
+                    (void)hipEventRecord(e, ctx->stream);
+                    block_done.push_back(e);
+                }
+            }
+            if (rc) break;
+        }
         if (params->flags & DRT_FLAG_FILM_ZERO)
         {
             /* Buffers that come zero-filled (the reference's alloc()) have usually never been touched: the download would then
@@ -1374,9 +1419,29 @@ extern "C" int drt_render_tile(const drt_scene *scene, const drt_camera *camera,
                 if (sizes[k]) ((volatile char *)bufs[k])[sizes[k] - 1] = 0;
             }
         }
-        if (verbose && (rc = drt_synchronize(ctx))) break;
+        if (verbose && !blocks_ok && (rc = drt_synchronize(ctx))) break;
         t[3] = wall_ms();
-        if ((rc = drt_read_film(ctx, dst_pixels, dst_avgs, dst_vars))) break;
+        bool fetched = false;
+        if (blocks_ok && block_done.size() == (size_t)((ctx->params.tile_h + per - 1) / per))
+        {
+            const size_t W = ctx->params.tile_w, S = scene->num_wavelengths;
+            const size_t words[3] = {xyz ? (size_t)XYZ_FILM_WORDS : S + 1, S, S};
+            double *host[3] = {dst_pixels, dst_avgs, dst_vars};
+            double *dev[3] = {ctx->d_pixels, ctx->d_avgs, ctx->d_vars};
+            fetched = true;
+            for (size_t k = 0; k < block_done.size() && fetched; k += 1)
+            {
+                if (hipEventSynchronize(block_done[k]) != hipSuccess) { fetched = false; break; }
+                unsigned long long st[4] = {0, 0, 0, 0}; /* pool cursor, overflow flag, last complete pair, peak */
+                if (hipMemcpy(st, ctx->d_counters + DRT_NUM_COUNTERS + 4, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess || (uint32_t)st[1] != 0u) { fetched = false; break; }
+                const size_t r0 = k * per, rows = std::min<size_t>(per, ctx->params.tile_h - r0);
+                for (int f = 0; f < 3; f += 1)
+                    if (host[f] && dev[f] && hipMemcpy(host[f] + r0 * W * words[f], dev[f] + r0 * W * words[f], rows * W * words[f] * 8, hipMemcpyDeviceToHost) != hipSuccess) fetched = false;
+            }
+        }
+        for (hipEvent_t e : block_done) (void)hipEventDestroy(e);
+        if ((rc = drt_synchronize(ctx))) break; /* timings, and what a pool that ran out left undone */
+        if (!fetched && (rc = drt_read_film(ctx, dst_pixels, dst_avgs, dst_vars))) break;
         if (stats && (rc = drt_get_stats(ctx, stats))) break;
         t[4] = wall_ms();
     } while (0);

@@ -305,6 +305,31 @@ def test_long_batches_and_work_queue_shapes_do_not_change_a_bit(monkeypatch):
             assert np.array_equal(a, b), "S=64 subs %d" % subs
 
 
+def test_one_shot_call_in_row_blocks_is_the_same_film(monkeypatch):
+    """drt_render_tile() renders a large tile (2^18 pixels and more) in row blocks, each with all its samples, so that a block's film rows
+    cross PCIe while the next block renders. In eight blocks, seven, two with a record pool that runs out on the way (the fall-back:
+    render again, fetch the film whole) and in one piece, the film is the session form's, bit for bit."""
+    bundle = pydrt.load_scene(cases.scene_path("cornell_plane_light.scn"), 512, 512)
+    p = pydrt.make_params(512, 512, spp=35, max_depth=6, seed=11, batch_spp=16)
+    r = pydrt.Renderer(bundle, p)
+    r.render(0, 35)
+    want = r.read_film()
+    st0 = r.stats()
+    r.close()
+    for env in ({}, {"DRT_ONESHOT_BLOCKS": "1"}, {"DRT_ONESHOT_BLOCKS": "7"}, {"DRT_POOL_BLOCKS": "1", "DRT_ONESHOT_BLOCKS": "2"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for flags in (pydrt.FLAG_FILM_ZERO, 0):
+            p1 = pydrt.make_params(512, 512, spp=35, max_depth=6, seed=11, batch_spp=16, flags=flags)
+            px, av, va, st = pydrt.render_tile(bundle, p1)
+            assert np.array_equal(px, want[0]) and np.array_equal(av, want[1]) and np.array_equal(va, want[2]), (env, flags)
+            assert (st.paths, st.shaded_vertices, st.rng_draws) == (st0.paths, st0.shaded_vertices, st0.rng_draws) or env.get("DRT_POOL_BLOCKS")
+            if env.get("DRT_POOL_BLOCKS"):
+                assert st.redone_launches >= 1
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_record_pool_that_runs_out_is_rendered_again_not_wrong(monkeypatch):
     """Vertex records live in a pool sized from the tile's measured blocks per path. If a launch needs more (forced here with
     a pool of one worst-case sample per pixel under launches of 12 samples), its shade kernel and everything queued behind it
