@@ -1158,6 +1158,36 @@ static int redo_batches(drt_context *ctx, uint64_t last_good_seq)
     return 0;
 }
 
+/* Samples [first_sample, first_sample + num_samples) of the tile in n_blocks row blocks, each with ALL the samples before the next
+ * block starts: a pair then covers fewer pixels and more samples of each (the record pool holds the same number of paths), and the
+ * film -- read and written once per pair, 3328 bytes a pixel -- is touched that much less often. Samples per pair: five eighths of
+ * what the pool's size would allow, because it is sized from the tile's AVERAGE path and the rows of an image that hold its objects
+ * run above that (a block that runs out anyway is rendered again: redo_batches). done[k], if asked for, is recorded behind block k. */
+static int enqueue_blocks(drt_context *ctx, uint32_t first_sample, uint32_t num_samples, uint32_t n_blocks, std::vector<hipEvent_t> *done)
+{
+    const uint32_t H = ctx->params.tile_h, W = ctx->params.tile_w;
+    const uint32_t per = (H + n_blocks - 1) / n_blocks;
+    const uint32_t n_blk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(num_samples, 4096), ctx->n_pix * (uint64_t)ctx->batch_spp * 5 / 8 / ((uint64_t)per * W)));
+    for (uint32_t r0 = 0; r0 < H; r0 += per)
+    {
+        const uint32_t rows = std::min(per, H - r0);
+        for (uint32_t at = 0; at < num_samples; at += n_blk)
+        {
+            const uint32_t n = std::min(n_blk, num_samples - at);
+            int rc = enqueue_pair(ctx, first_sample + at, n, 0, r0, rows, n);
+            if (rc) return rc;
+        }
+        if (done)
+        {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            done->push_back(e);
+            HIP_TRY(hipEventRecord(e, ctx->stream));
+        }
+    }
+    return 0;
+}
+
 extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_samples)
 {
     if (!ctx) return fail(-1, "null context");
@@ -1182,6 +1212,16 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
     {
         int rc = drt_synchronize(ctx);
         if (rc) return rc;
+    }
+    /* More samples than one pair takes over the whole tile, on a tile so large that a pair takes few samples of each pixel: row blocks,
+     * so that the film is passed over fewer times (config 5, 4096^2 at 16 samples a pair: 208 bytes of film per path; in blocks
+     * 1141 -> 1196 Mpaths/s). Where a pair takes 32 samples or more the film is a small part of the traffic and the smaller launches
+     * cost more than they save (1024^2, 64 a pair: 1493 -> 1452). Not with the hit log on, which is laid out by sample of the whole tile. */
+    if (!(p.flags & DRT_FLAG_RECORD_HITS) && num_samples > ctx->batch_spp && ctx->batch_spp < 32 && p.tile_h >= 64 && !getenv("DRT_NO_ROW_BLOCKS"))
+    {
+        const uint64_t want = ((uint64_t)num_samples * 8 + (uint64_t)ctx->batch_spp * 5 - 1) / ((uint64_t)ctx->batch_spp * 5); /* blocks for one pair each */
+        const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(want, 16), p.tile_h / 16);
+        if (n_blocks > 1) return enqueue_blocks(ctx, first_sample, num_samples, n_blocks, nullptr);
     }
     for (uint32_t done = 0; done < num_samples; done += ctx->batch_spp)
     {
@@ -1371,7 +1411,6 @@ extern "C" int drt_render_tile(const drt_scene *scene, const drt_camera *camera,
          * quarter of the rows takes four times the samples), so that a block's film rows cross PCIe while the next block renders:
          * what is left exposed of the 1.7 GB download is its last quarter. (A pool that runs out on the way: drt_synchronize
          * renders again from there, and the film is fetched whole.) */
-        const uint32_t B = ctx->batch_spp;
         uint32_t n_blocks = 8; /* 1024^2 x 256 spp, wall: 226 ms in one piece, 219 / 214 / 206 ms in 2 / 4 / 8 blocks (kernels 187 -> 197 ms: smaller launches) */
         if (getenv("DRT_ONESHOT_BLOCKS")) n_blocks = (uint32_t)std::max(1, atoi(getenv("DRT_ONESHOT_BLOCKS")));
         const uint32_t per = (ctx->params.tile_h + n_blocks - 1) / n_blocks; /* rows per block */
@@ -1382,28 +1421,7 @@ extern "C" int drt_render_tile(const drt_scene *scene, const drt_camera *camera,
         {
             if ((rc = drt_render(ctx, params->first_sample, params->spp))) break;
         }
-        else
-        {
-            /* samples per pair: five eighths of the paths of a full-tile pair over this block's pixels -- the pool is sized from the
-             * tile's AVERAGE path, and some rows of an image (the ones with the objects in them) run well above it */
-            const uint32_t n_blk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(params->spp, 4096), ctx->n_pix * (uint64_t)B * 5 / 8 / ((uint64_t)per * ctx->params.tile_w)));
-            for (uint32_t r0 = 0; r0 < ctx->params.tile_h && !rc; r0 += per)
-            {
-                const uint32_t rows = std::min(per, ctx->params.tile_h - r0);
-                for (uint32_t done = 0; done < params->spp && !rc; done += n_blk)
-                {
-                    const uint32_t n = std::min(n_blk, params->spp - done);
-                    rc = enqueue_pair(ctx, params->first_sample + done, n, 0, r0, rows, n);
-                }
-                hipEvent_t e;
-                if (!rc && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess)
-                {
-                    (void)hipEventRecord(e, ctx->stream);
-                    block_done.push_back(e);
-                }
-            }
-            if (rc) break;
-        }
+        else if ((rc = enqueue_blocks(ctx, params->first_sample, params->spp, n_blocks, &block_done))) break;
         if (params->flags & DRT_FLAG_FILM_ZERO)
         {
             /* Buffers that come zero-filled (the reference's alloc()) have usually never been touched: the download would then
