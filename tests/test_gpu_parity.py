@@ -328,6 +328,47 @@ def test_one_shot_call_in_row_blocks_is_the_same_film(monkeypatch):
                 assert st.redone_launches >= 1
         for k in env:
             monkeypatch.delenv(k)
+    # a tile of every other row (what a rank of two renders), and the XYZ film: blocks against one piece
+    tall = pydrt.load_scene(cases.scene_path("cornell_plane_light.scn"), 512, 1024)
+    for kw in (dict(height=1024, y0=1, tile_h=512, row_stride=2), dict(height=512, mode=pydrt.MODE_XYZ)):
+        got = []
+        bundle = tall if kw["height"] == 1024 else pydrt.load_scene(cases.scene_path("cornell_plane_light.scn"), 512, 512)
+        for blocks in ("8", "1"):
+            monkeypatch.setenv("DRT_ONESHOT_BLOCKS", blocks)
+            pk = pydrt.make_params(512, spp=9, max_depth=5, seed=4, batch_spp=4, flags=pydrt.FLAG_FILM_ZERO, **kw)
+            if kw.get("mode") == pydrt.MODE_XYZ:
+                L = pydrt.hip_lib()
+                acc = np.zeros((512 * 512, 8))
+                st = pydrt.Stats()
+                assert L.drt_render_tile(C.byref(bundle.scene), C.byref(bundle.camera), C.byref(pk), acc.ctypes.data_as(C.POINTER(C.c_double)), None, None, C.byref(st)) == 0
+                got.append((acc,))
+            else:
+                got.append(pydrt.render_tile(bundle, pk)[:3])
+            monkeypatch.delenv("DRT_ONESHOT_BLOCKS")
+        assert all(np.array_equal(a, b) for a, b in zip(got[0], got[1])), kw
+        assert float(np.abs(got[0][0]).sum()) > 0.0
+
+
+def test_render_in_row_blocks_is_the_same_film(monkeypatch):
+    """A drt_render() call for more samples than a kernel pair takes, on a context whose pairs take few samples of a pixel, goes out in
+    row blocks (each with all the call's samples) so that the film is passed over less often: same film, same statistics."""
+    bundle = pydrt.load_scene(cases.scene_path("cornell_plane_light.scn"), 96, 200)
+    p = pydrt.make_params(96, 200, spp=23, max_depth=7, seed=2, batch_spp=3)
+    films = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("DRT_NO_ROW_BLOCKS", "1")
+        r = pydrt.Renderer(bundle, p)
+        r.render(0, 20)
+        r.render(20, 3)
+        films.append(r.read_film() + (r.stats(),))
+        r.close()
+    monkeypatch.delenv("DRT_NO_ROW_BLOCKS")
+    for a, b in zip(films[0][:3], films[1][:3]):
+        assert np.array_equal(a, b)
+    assert (films[0][3].paths, films[0][3].rng_draws, films[0][3].shaded_vertices) == (films[1][3].paths, films[1][3].rng_draws, films[1][3].shaded_vertices)
+    opx = O.oracle_render_tile(bundle, p, math_mode=O.MATH_DEVICE, num_threads=4)[0]
+    assert cases.rel_err(films[0][0], opx) <= FILM_TOL
 
 
 def test_record_pool_that_runs_out_is_rendered_again_not_wrong(monkeypatch):
