@@ -468,7 +468,7 @@ __device__ __forceinline__ EvalCoef eval_coefficients(const DevScene &sc, const 
     {
         V3 bisector = v_normalise(v_sum(ip.out, in));
         double nb = v_dot(ip.normal, bisector);
-        e.spec = pow((0.0 > nb) ? 0.0 : nb, mat.shininess);
+        e.spec = drt_pow_shininess((0.0 > nb) ? 0.0 : nb, mat.shininess);
     }
     if (needs & NEED_EQR) /* :123-124, :136-137, :150-151 */
     {
@@ -1958,6 +1958,7 @@ __global__ void drt_selftest_kernel(int op, const double *a, const double *b, do
             break;
         }
         case 3: out[i] = pow(a[i], b[i]); break;
+        case 7: out[i] = drt_pow_shininess(a[i], b[i]); break; /* the glossy lobe's power (csrc/drt_device.h) */
         case 4:
         {
             uint64_t key = (uint64_t)__double_as_longlong(a[i]);
