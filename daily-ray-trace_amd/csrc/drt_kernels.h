@@ -1549,12 +1549,13 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                  * path's further blocks one at a time -- four vertices by ONE coalesced load, which takes the place of vertices 0-3
                  * in this sample's LDS slot, then the same loop (visibility from the light's flag word, the header has 8 bits). A
                  * round trip per block instead of one per vertex, and none of the general loop's work. */
-                if (run == 2u * REC_BLOCK_VERTICES && n_shaded > run && vw * REC_BLOCK_VERTICES == 64u)
+                if (run == n_fast && n_shaded > run && vw * REC_BLOCK_VERTICES == 64u)
                 {
                     const uint64_t h3s = readlane64(h3, s);
-                    for (uint32_t b = 2u; b * REC_BLOCK_VERTICES < n_shaded && b < 4u; b += 1) /* plastic_mask covers 16 vertices */
+                    for (uint32_t b = n_fast / REC_BLOCK_VERTICES; b * REC_BLOCK_VERTICES < n_shaded && b < 4u; b += 1) /* plastic_mask covers 16 vertices */
                     {
                         uint32_t id = (uint32_t)h3s;
+                        if (b == 1u) id = (uint32_t)(readlane64(h2, s) >> 32);
                         if (b >= REC_HEADER_BLOCKS) id = ((const uint32_t *)(records + (uint64_t)(uint32_t)(h3s >> 32) * sp.block_words))[b - REC_HEADER_BLOCKS];
                         const uint64_t blockw = records[(uint64_t)id * sp.block_words + lane];
                         uint64_t *slot = rec_lds + (s & 1u) * (64u * SHADE_PREFETCH_REGS);
