@@ -1536,13 +1536,13 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                     reflectance = reflectance * dir_pdf;         /* :468 */
                     throughput[0] = throughput[0] * reflectance; /* :469 */
                 };
-                for (uint32_t v = 0; v < run; v += 1)
-                {
-                    const uint32_t idx = (v * vw + 1u) & 63u;
-                    const uint64_t wa = readlane64(cur[0], idx);
-                    const uint64_t wb = readlane64(cur[SHADE_PREFETCH_REGS > 1 ? 1 : 0], idx);
-                    run_vertex((v < vpr) ? wa : wb, rec_words + v * vw, ((vis0_mask >> v) & 1u) != 0u);
-                }
+                /* the vertices the first prefetch register holds, then those of the second: the word with the SPD indices comes out of
+                 * ONE register by v_readlane, no choosing between two */
+                const uint32_t run0 = run < vpr ? run : vpr;
+                for (uint32_t v = 0; v < run0; v += 1)
+                    run_vertex(readlane64(cur[0], v * vw + 1u), rec_words + v * vw, ((vis0_mask >> v) & 1u) != 0u);
+                for (uint32_t v = run0; v < run; v += 1)
+                    run_vertex(readlane64(cur[SHADE_PREFETCH_REGS > 1 ? 1 : 0], (v - vpr) * vw + 1u), rec_words + v * vw, ((vis0_mask >> v) & 1u) != 0u);
                 v_first = run;
 #if DRT_SHADE_DEEP_BLOCKS
                 /* Beyond the prefetched records (vertices 8 and up: long paths in closed scenes), when everything so far was a run: the
