@@ -1069,7 +1069,9 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
 #define SHADE_PREFETCH_REGS 2 /* 64-word registers per path: 128 record words are prefetched, deeper paths fall back */
 #endif
 #ifndef SHADE_PREFETCH_DEPTH
-#define SHADE_PREFETCH_DEPTH 2 /* samples whose record loads are in flight ahead of the one being replayed */
+#define SHADE_PREFETCH_DEPTH 1 /* samples whose record loads are in flight ahead of the one being replayed. Latency is hidden by the other
+                                  waves at any depth (the kernel is bound by what it issues); one ahead is the fewest
+                                  register moves and LDS writes: 106.0 ms against 106.8 with two */
 #endif
 #ifndef DRT_SHADE_DEEP_BLOCKS
 #define DRT_SHADE_DEEP_BLOCKS 1 /* plastic runs continue past the prefetched records, a block (four vertices) per load */
@@ -1476,6 +1478,15 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
             /* The records of the sample AFTER this one (requested a sample ago) go to this wave's LDS slot (s + 1) & 1: the
              * coefficient words of a plastic vertex are then read back as broadcast LDS loads -- one instruction per 64-bit word,
              * result in a vector register where the f64 operations want it -- instead of two v_readlane each. */
+#if SHADE_PREFETCH_DEPTH == 1
+            if (n_shaded != 0u)
+            {
+                /* one sample ahead: the slot gets THIS sample's records (the next one's are still on their way) */
+                uint64_t *slot_now = rec_lds + (s & 1u) * (64u * SHADE_PREFETCH_REGS);
+#pragma unroll
+                for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) slot_now[64u * k + lane] = ring[0][k];
+            }
+#else
             {
                 uint64_t *slot_next = rec_lds + ((s + 1u) & 1u) * (64u * SHADE_PREFETCH_REGS);
 #pragma unroll
@@ -1486,6 +1497,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                     for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) rec_lds[64u * k + lane] = ring[0][k];
                 }
             }
+#endif
             const uint64_t *rec_words = rec_lds + (s & 1u) * (64u * SHADE_PREFETCH_REGS);
 #endif
 
