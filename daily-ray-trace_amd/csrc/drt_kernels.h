@@ -1478,7 +1478,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
             /* The records of the sample AFTER this one (requested a sample ago) go to this wave's LDS slot (s + 1) & 1: the
              * coefficient words of a plastic vertex are then read back as broadcast LDS loads -- one instruction per 64-bit word,
              * result in a vector register where the f64 operations want it -- instead of two v_readlane each. */
-#if SHADE_PREFETCH_DEPTH == 1
+#if SHADE_PREFETCH_DEPTH <= 1
             if (n_shaded != 0u)
             {
                 /* one sample ahead: the slot gets THIS sample's records (the next one's are still on their way) */
