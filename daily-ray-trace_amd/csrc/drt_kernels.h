@@ -151,6 +151,8 @@ struct DevCamera
 #define REC_BLOCK_VERTICES (1u << REC_BLOCK_SHIFT)
 #define REC_HEADER_BLOCKS 3 /* blocks named in the header itself; further ones through the table block */
 #define HDR_TERM_NOT_DONE 0x80u /* header `term` byte of a path that found the pool exhausted */
+#define HDR_TERM_TAIL_STAGED 0x40u /* header `term` byte, or'ed in: the trace kernel has put the path's tail wavelengths into tail_stage */
+#define HDR_TERM_MASK 0x3Fu
 #define REC_VERTEX_WORDS 10
 #define REC_LIGHT_WORDS 6
 #define FLAG_EQR 1u
@@ -169,6 +171,10 @@ struct TraceParams
     uint32_t chunk, pool_blocks;         /* path ids a wave draws from the work counter at a time (multiple of 64); blocks in the pool */
     unsigned long long *pool_cursor;     /* next free block of the pool (reset before every trace launch) */
     uint32_t *overflow;                  /* set when the pool ran out: this launch's records are incomplete */
+    /* the tail wavelengths (S mod 64 of them) of plastic-only paths, done here: see "Tail wavelengths in the trace kernel" */
+    double       *tail_stage;            /* [n_pix * batch][tail_count] per-sample values the shade kernel's film phase reads; NULL: off */
+    const double *spd_tail;              /* [n_spd][tail_count]: the SPD table's tail columns */
+    uint32_t      tail_count, n_spd;
 };
 
 /* A wave's share of the pool. Waves take POOL_CHUNK blocks at a time from the global cursor and hand them to their lanes by
@@ -644,7 +650,7 @@ __device__ __forceinline__ void camera_ray(const DevCamera &cam, uint32_t scheme
 
 /* LDS carve-up (8-byte aligned): surfaces, lights, then u32 tables, then materials (see trace_lds_bytes in the launcher) */
 
-template <bool SCENE_IN_LDS>
+template <bool SCENE_IN_LDS, bool TAIL = false>
 __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_trace_kernel(DevScene sc, DevCamera cam, TraceParams tp,
                                                                  uint64_t *__restrict__ records, uint64_t *__restrict__ headers,
                                                                  int32_t *__restrict__ hits, unsigned long long *__restrict__ counters,
@@ -701,6 +707,28 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
         sv.bvh_leaf = sc.bvh_leaf;
     }
 
+    /*
+     * Tail wavelengths in the trace kernel. The shade kernel's lanes are wavelengths, and the S mod 64 that do not fill a wave (5 on
+     * the reference grid) cost it a pass of their own in which a lane must decode records by itself. HERE a lane is a path and
+     * already holds every number a vertex contributes, so the same arithmetic for those few wavelengths is a handful of f64
+     * operations per vertex at full lane use. It is done for paths that consist of two-lobe plastic vertices only (and for paths
+     * without a vertex): running throughput and radiance per tail wavelength live in LDS (a wave's block: [2 R][64 lanes]), the
+     * table's tail columns too, and when the path ends its values go to tail_stage, flagged in the header. The launcher uses this
+     * instantiation only for scenes in which EVERY material is one of the two (then the shade kernel's tail pass has no path to
+     * replay and only updates the film: ShadeParams::tail_staged); a path that met any other material would stay unflagged.
+     * Same operations in the same order as drt_shade_kernel's (src/daily_ray_trace.c:440-472, :615).
+     */
+    const uint32_t TR = tp.tail_count;
+    const bool tail_on = TAIL && SCENE_IN_LDS && tp.tail_stage != nullptr; /* TAIL: an instantiation of its own, so that scenes that cannot use it run the kernel without any of this */
+    double *l_spd_tail = nullptr, *tail_state = nullptr;
+    if (tail_on)
+    {
+        l_spd_tail = (double *)(sv.mats + sc.n_mat); /* behind the LDS copy of the materials, the last of the scene's tables */
+        for (uint32_t k = threadIdx.x; k < tp.n_spd * TR; k += TRACE_BLOCK) l_spd_tail[k] = tp.spd_tail[k];
+        tail_state = l_spd_tail + (size_t)tp.n_spd * TR + (size_t)(threadIdx.x >> 6) * (2u * TR * 64u) + (threadIdx.x & 63u);
+        __syncthreads();
+    }
+    bool tail_ok = false; /* per lane: the path's tail wavelengths are being carried here */
     const uint32_t lane = threadIdx.x & 63u;
     /* per-wave work queue: a wave draws chunks of consecutive path ids from the global counter and
      * deals them to its idle lanes by ballot + prefix count */
@@ -800,6 +828,13 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
                 shaded = 0;
                 plastic_mask = 0;
                 vis0_mask = 0;
+                tail_ok = tail_on;
+                if (tail_on)
+                    for (uint32_t j = 0; j < TR; j += 1)
+                    {
+                        tail_state[(2u * j) * 64u] = 1.0;      /* throughput, const_spectrum(throughput, 1.0), :440 */
+                        tail_state[(2u * j + 1u) * 64u] = 0.0; /* dst */
+                    }
                 uint64_t slot = q * (uint64_t)tp.batch + s_local;
                 hdr = headers + slot * REC_HEADER_WORDS;
                 /* vignette: dot(ray_direction, forward) of the PRIMARY ray, src/daily_ray_trace.c:614 */
@@ -843,6 +878,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
                 uint64_t *vrec = records + (uint64_t)blk * tp.block_words + (uint64_t)(shaded & (REC_BLOCK_VERTICES - 1u)) * tp.vertex_words;
                 /* direct_light_contribution, :272-332 -- light samples are drawn before the shadow test */
                 n_shaded += 1;
+                bool t_vis = false; /* light 0 as the tail arithmetic below wants it (the kernel carries tails only in one-light scenes) */
+                double t_c = 0.0, t_a_in = 0.0, t_spec = 0.0;
+                uint32_t t_em = 0, t_flags = 0;
                 for (uint32_t l = 0; l < sv.n_lights; l += 1)
                 {
                     uint32_t ltype = sv.light_type[l];
@@ -887,15 +925,77 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
                         double c = attenuation * (light_pdf);
                         lrec[1] = (uint64_t)__double_as_longlong(c);
                         store_coef(lrec + 2, e);
+                        if (l == 0) { t_vis = true; t_c = c; t_a_in = e.a_in; t_spec = e.spec; t_flags = e.flags; }
                     }
                     uint32_t em_spd = (uint32_t)sv.mats[sv.light_mat[l]].emission_spd & 0xFFFFu;
                     lrec[0] = (uint64_t)em_spd | ((uint64_t)lflags << 16);
+                    if (l == 0) t_em = em_spd;
                 }
                 /* sampled continuation, :464-472 */
                 V3 in;
                 double dir_pdf;
                 sample_direction(sc, sv, ip, rs, n_draws, in, dir_pdf);
                 EvalCoef e = eval_coefficients(sc, sv, ip, in);
+                if (tail_ok)
+                {
+                    if (mat.vertex_flags & FLAG_PLASTIC)
+                    {
+                        /* bdsf() over {bp_diffuse_bdsf, bp_glossy_bdsf} at the tail wavelengths, as drt_shade_kernel's plastic_vertex */
+                        const double *row_d = l_spd_tail + ((uint32_t)mat.diffuse_spd & 0xFFFFu) * TR;
+                        const double *row_g = l_spd_tail + ((uint32_t)mat.glossy_spd & 0xFFFFu) * TR;
+                        const double *row_e = l_spd_tail + t_em * TR;
+                        for (uint32_t j = 0; j < TR; j += 1)
+                        {
+                            const double diffuse_pi = row_d[j], glossy = row_g[j];
+                            double throughput = tail_state[(2u * j) * 64u], dst = tail_state[(2u * j + 1u) * 64u];
+                            double contribution = 0.0;
+                            if (t_vis)
+                            {
+                                double reflectance = diffuse_pi * t_a_in + 0.0;
+                                reflectance = (glossy * t_spec) * t_a_in + reflectance;
+                                contribution = contribution + reflectance; /* :323 */
+                                contribution = contribution * row_e[j];    /* :324 */
+                                contribution = contribution * t_c;         /* :326-327 */
+                            }
+                            dst = dst + throughput * contribution; /* :461-462 */
+                            double reflectance = diffuse_pi * e.a_in + 0.0;
+                            reflectance = (glossy * e.spec) * e.a_in + reflectance;
+                            reflectance = reflectance * dir_pdf; /* :468 */
+                            throughput = throughput * reflectance; /* :469 */
+                            tail_state[(2u * j) * 64u] = throughput;
+                            tail_state[(2u * j + 1u) * 64u] = dst;
+                        }
+                    }
+                    else if (mat.num_bdsfs == 1u && mat.bdsfs[0] == DRT_BDSF_mirror_bdsf)
+                    {
+                        /* bdsf() over {mirror_bdsf}: the mirror's spectrum where the direction is the mirror direction exactly, else 0
+                         * (src/bdsf.c:121-132) -- as bdsf_at_wavelength() in drt_shade_kernel */
+                        const double *row_m = l_spd_tail + ((uint32_t)mat.mirror_spd & 0xFFFFu) * TR;
+                        const double *row_e = l_spd_tail + t_em * TR;
+                        for (uint32_t j = 0; j < TR; j += 1)
+                        {
+                            const double mirror = row_m[j];
+                            double throughput = tail_state[(2u * j) * 64u], dst = tail_state[(2u * j + 1u) * 64u];
+                            double contribution = 0.0;
+                            if (t_vis)
+                            {
+                                double bdsf_result = (t_flags & FLAG_EQR) ? mirror : 0.0;
+                                double reflectance = bdsf_result + 0.0;
+                                contribution = contribution + reflectance;
+                                contribution = contribution * row_e[j];
+                                contribution = contribution * t_c;
+                            }
+                            dst = dst + throughput * contribution;
+                            double bdsf_result = (e.flags & FLAG_EQR) ? mirror : 0.0;
+                            double reflectance = bdsf_result + 0.0;
+                            reflectance = reflectance * dir_pdf;
+                            throughput = throughput * reflectance;
+                            tail_state[(2u * j) * 64u] = throughput;
+                            tail_state[(2u * j + 1u) * 64u] = dst;
+                        }
+                    }
+                    else tail_ok = false; /* any other material: the shade kernel's tail pass replays this path */
+                }
                 vrec[0] = mat.bdsf_packed;
                 vrec[1] = (uint64_t)mat.num_bdsfs | ((uint64_t)(e.flags | mat.vertex_flags) << 8) | ((uint64_t)((uint32_t)mat.diffuse_spd & 0xFFFFu) << 16) |
                           ((uint64_t)((uint32_t)mat.glossy_spd & 0xFFFFu) << 32) | ((uint64_t)((uint32_t)mat.mirror_spd & 0xFFFFu) << 48);
@@ -913,7 +1013,22 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
             depth += 1;
             if (terminal || depth >= tp.max_depth)
             {
-                hdr[0] = (uint64_t)shaded | ((uint64_t)term << 16) | ((uint64_t)(term_spd & 0xFFFFu) << 32) | ((uint64_t)plastic_mask << 48) | ((uint64_t)vis0_mask << 24);
+                uint32_t staged = 0;
+                if (tail_ok)
+                {
+                    /* the sample's value at the tail wavelengths: emission of what the path ended on, vignette (:452-457, :615) */
+                    const double vignette = __longlong_as_double((long long)hdr[1]);
+                    double *st = tp.tail_stage + (uint64_t)(hdr - headers) / REC_HEADER_WORDS * TR;
+                    const double *row_t = l_spd_tail + (term_spd & 0xFFFFu) * TR;
+                    for (uint32_t j = 0; j < TR; j += 1)
+                    {
+                        double dst = tail_state[(2u * j + 1u) * 64u];
+                        if (term == 1) dst = dst + tail_state[(2u * j) * 64u] * row_t[j];
+                        st[j] = dst * vignette;
+                    }
+                    staged = HDR_TERM_TAIL_STAGED;
+                }
+                hdr[0] = (uint64_t)shaded | ((uint64_t)(term | staged) << 16) | ((uint64_t)(term_spd & 0xFFFFu) << 32) | ((uint64_t)plastic_mask << 48) | ((uint64_t)vis0_mask << 24);
                 alive = false;
             }
         }
@@ -954,7 +1069,8 @@ struct ShadeParams
     uint32_t vertex_shift, pad3; /* log2(vertex_words) */
     uint32_t tail_first, tail_count; /* wavelengths [tail_first, tail_first + tail_count) go through the packed tail pass (0: none) */
     uint32_t chunk, sub_pixels;      /* pixels per group (= tail packing size when there is a tail); pixels per main-pass work item */
-    uint32_t light0_em_spd, pad2;         /* emission SPD row of light 0 (what every light block of light 0 says) */
+    uint32_t light0_em_spd, tail_staged;  /* emission SPD row of light 0 (what every light block of light 0 says); tail_staged: the trace
+                                             kernel has put every path's tail wavelengths into tail_stage, the tail pass only updates the film */
     double  *tail_stage;                  /* [n_pix * batch][tail_count]: per-sample results of the tail pass (see the kernel) */
     uint32_t cmf_rw, cmf_x, cmf_y, cmf_z; /* XYZ film mode: SPD rows of the white table and the colour-matching functions */
     uint32_t tail_period_mains, pad1;  /* split queue with a tail: main-pass items between two tail items (<= main items per group) */
@@ -1138,6 +1254,7 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
         throughput = 1.0;
         dst = 0.0;
     };
+    if (sp.tail_staged) s = sp.n_samples; /* nothing to replay: drt_trace_kernel<true, true> staged every sample */
     if (s < sp.n_samples) open_sample();
     while (__any(s < sp.n_samples))
     {
@@ -1251,7 +1368,7 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
         if (s < sp.n_samples && v >= n_shaded)
         {
             /* the path's last vertex is done (or it had none): close the sample, :452-457 and :615 */
-            if (((uint32_t)(ph0 >> 16) & 0xFFu) == 1u) dst = dst + throughput * spd_at(table, S, (uint32_t)(ph0 >> 32) & 0xFFFFu, lam);
+            if (((uint32_t)(ph0 >> 16) & HDR_TERM_MASK) == 1u) dst = dst + throughput * spd_at(table, S, (uint32_t)(ph0 >> 32) & 0xFFFFu, lam);
             sp.tail_stage[((chunk_base + g) * (uint64_t)sp.batch + s) * R + j] = dst * vignette; /* the address from scratch: a pointer kept live costs two registers */
             s += 1;
             if (s < sp.n_samples) open_sample();
@@ -1459,7 +1576,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
             const uint64_t hs = readlane64(h0, s);
             const double vignette = word_as_double(readlane64(h1, s));
             const uint32_t n_shaded = (uint32_t)(hs & 0xFFFFu);
-            const uint32_t term = (uint32_t)(hs >> 16) & 0xFFu;
+            const uint32_t term = (uint32_t)(hs >> 16) & HDR_TERM_MASK;
             const uint32_t term_spd = (uint32_t)(hs >> 32) & 0xFFFFu;
             const uint32_t plastic_mask = (uint32_t)(hs >> 48); /* bit v: vertex v has the two-lobe plastic list */
             const uint32_t vis0_mask = (uint32_t)(hs >> 24) & 0xFFu; /* bit v (< 8): light 0 visible from vertex v */

@@ -77,6 +77,8 @@ struct drt_context
     int         primary_grid_cap = 0, bounce_grid_cap = 0;
     double   *d_xyz = nullptr;
     uint8_t  *d_bgra = nullptr;
+    bool      trace_tail = false;     /* the trace kernel carries the tail wavelengths of every path (drt_trace_kernel<true, true>) */
+    const double *d_spd_tail = nullptr; /* [n_spd][tail_count]: the SPD table's tail columns */
 
     bool   scene_in_lds = true, spds_in_lds = true, use_bvh = false;
     size_t trace_lds = 0, shade_lds = 0;
@@ -350,6 +352,8 @@ struct BvhBuilder
     }
 };
 
+static void shade_sets(uint32_t S, uint32_t *n_sets, uint32_t *tail_first, uint32_t *tail_count);
+
 static int build_device_scene(drt_context *ctx, const drt_scene *scene, double reach)
 {
     const uint32_t S = scene->num_wavelengths;
@@ -547,6 +551,33 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene, double r
     }
     if (!ctx->scene_in_lds) ctx->trace_lds = 0;
     ctx->spds_in_lds = (size_t)d.n_spd * S * 8 <= 64 * 1024;
+    /* The tail wavelengths in the trace kernel (csrc/drt_kernels.h, drt_trace_kernel<true, true>): scenes scanned out of LDS with one
+     * light and a tail of at most 8 wavelengths, in which every surface is a light, a black body, two-lobe plastic or a mirror -- so
+     * that EVERY path's tail is staged there and the shade kernel's tail pass has nothing to replay -- when the table's tail columns
+     * and the waves' running values ([2 R][64 lanes] each) fit beside the scene. (With glass or gold in the scene the paths that
+     * touch them would stay with the tail pass, and the scheme as a whole measured no gain: DESIGN.md section 7.) */
+    {
+        uint32_t sets = 0, tf = 0, tc = 0;
+        shade_sets(S, &sets, &tf, &tc);
+        const size_t extra = (size_t)d.n_spd * tc * 8 + (size_t)(TRACE_BLOCK / 64) * 2 * tc * 64 * 8;
+        bool all_simple = true;
+        for (uint32_t i = 0; i < n_surf; i += 1)
+        {
+            const DevMaterial &m = mats[smat[i]];
+            const bool mirror_only = m.num_bdsfs == 1u && m.bdsfs[0] == DRT_BDSF_mirror_bdsf;
+            if (!(m.is_black_body || (m.vertex_flags & FLAG_PLASTIC) || mirror_only)) all_simple = false;
+        }
+        const char *e = getenv("DRT_TRACE_TAIL");
+        ctx->trace_tail = ctx->scene_in_lds && sets == 1 && tc > 0 && tc <= 8 && n_lights == 1 && all_simple && ctx->trace_lds + extra <= 48 * 1024 && !(e && *e == '0');
+        if (ctx->trace_tail)
+        {
+            std::vector<double> cols((size_t)d.n_spd * tc);
+            for (uint32_t r = 0; r < d.n_spd; r += 1)
+                for (uint32_t j = 0; j < tc; j += 1) cols[(size_t)r * tc + j] = spds[(size_t)r * S + tf + j];
+            if ((rc = upload(ctx, cols, &ctx->d_spd_tail))) return rc;
+            ctx->trace_lds += extra;
+        }
+    }
     return 0;
 }
 
@@ -729,7 +760,7 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
     int per_cu = 0;
     if (ctx->scene_in_lds)
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, drt_trace_kernel<true>, TRACE_BLOCK, ctx->trace_lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, drt_trace_kernel<true, false>, TRACE_BLOCK, ctx->trace_lds));
     if (per_cu < 1) per_cu = 1;
     if (const char *e = getenv("DRT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e)); /* tuning knob */
     ctx->trace_grid_cap = prop.multiProcessorCount * per_cu;
@@ -1012,6 +1043,10 @@ static int enqueue_trace(drt_context *ctx, uint32_t first_sample, uint32_t n, ui
     tp.hits_sample_offset = hits_sample_offset;
     tp.batch = stride ? stride : ctx->batch_spp; /* sample slots per pixel in the header array (a launch over fewer rows may take more samples) */
     tp.pool_blocks = (uint32_t)ctx->pool_blocks;
+    tp.tail_stage = ctx->trace_tail ? ctx->d_tail_stage : nullptr;
+    tp.spd_tail = ctx->d_spd_tail;
+    tp.tail_count = ctx->tail_count;
+    tp.n_spd = ctx->dsc.n_spd;
     unsigned long long *work = ctx->d_counters + DRT_NUM_COUNTERS;
     tp.pool_cursor = work + 4;
     tp.overflow = (uint32_t *)(work + 5);
@@ -1037,8 +1072,11 @@ static int enqueue_trace(drt_context *ctx, uint32_t first_sample, uint32_t n, ui
         hipLaunchKernelGGL(drt_bounce_kernel, dim3(grid), dim3(BOUNCE_BLOCK), 0, ctx->stream, ctx->dsc, ctx->dcam, tp, ctx->d_records,
                            ctx->d_headers, ctx->d_hits, ctx->d_counters, work, ctx->d_primary, ctx->d_queue, work + 2);
     }
+    else if (ctx->trace_tail && tp.tail_stage)
+        hipLaunchKernelGGL((drt_trace_kernel<true, true>), dim3(grid), dim3(TRACE_BLOCK), ctx->trace_lds, ctx->stream, ctx->dsc,
+                           ctx->dcam, tp, ctx->d_records, ctx->d_headers, ctx->d_hits, ctx->d_counters, work);
     else
-        hipLaunchKernelGGL(drt_trace_kernel<true>, dim3(grid), dim3(TRACE_BLOCK), ctx->trace_lds, ctx->stream, ctx->dsc,
+        hipLaunchKernelGGL((drt_trace_kernel<true, false>), dim3(grid), dim3(TRACE_BLOCK), ctx->trace_lds, ctx->stream, ctx->dsc,
                            ctx->dcam, tp, ctx->d_records, ctx->d_headers, ctx->d_hits, ctx->d_counters, work);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1071,6 +1109,7 @@ static int enqueue_pair(drt_context *ctx, uint32_t first_sample, uint32_t n, uin
     sp.tail_count = ctx->tail_count;
     sp.tail_stage = ctx->d_tail_stage;
     sp.light0_em_spd = ctx->light0_em_spd;
+    sp.tail_staged = (ctx->trace_tail && ctx->d_tail_stage) ? 1u : 0u;
     sp.cmf_rw = ctx->cmf_rw; sp.cmf_x = ctx->cmf_x; sp.cmf_y = ctx->cmf_y; sp.cmf_z = ctx->cmf_z;
     sp.chunk = ctx->tail_count ? 64u / ctx->tail_count : SHADE_PIXEL_CHUNK;
     uint64_t groups = (n_pix + sp.chunk - 1) / sp.chunk;
