@@ -3,6 +3,8 @@
 
 Metric (BASELINE.json): Mpaths/s (pixels*spp/s), Cornell 1024^2, depth 8 -- cornell_plane_light.scn at
 1024x1024, 256 spp, max depth 8 (BASELINE configs[1]); plus the roofline fraction of the dominant kernel.
+`--workload config3` (cornell_large_box 2048^2, 1024 spp, depth 16: BASELINE configs[2], the one it asks to tile over
+8 GPUs), `config4` and `config5` run the other BASELINE configs through the same code; the default is the headline.
 
 A "step" is one full render of that frame: every sample of every pixel through the trace and the shade+film
 kernels, with scene, SPD tables and film resident in HBM when the clock starts. With N > 1 GPUs the frame is
@@ -29,6 +31,34 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, "daily-ray-trace_amd"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+# BASELINE.json configs[1..4] as (scene, image size, samples per pixel, max depth); "@spheres:N" = the synthetic generator
+WORKLOADS = {
+    "config2": ("cornell_plane_light.scn", 1024, 256, 8, "BASELINE configs[1]"),
+    "config3": ("cornell_large_box.scn", 2048, 1024, 16, "BASELINE configs[2]"),
+    "config4": ("cornell_gold_mirror.scn", 1024, 512, 8, "BASELINE configs[3]"),
+    "config5": ("@spheres:10000", 4096, 64, 8, "BASELINE configs[4]"),
+}
+
+
+def load_workload_scene(scene, W, H):
+    import pydrt
+    if scene.startswith("@spheres:"):
+        return pydrt.synthetic_sphere_scene(int(scene.split(":")[1]), W, H)
+    return pydrt.load_scene(os.path.join(REPO, "scenes", scene), W, H)
+
+
+def csrc_sha():
+    """sha256 over the kernel sources: stamps profiles/roofline*.json (tools/roofline_from_profiles.py), so that per-path counters
+    taken from an OLDER build of the kernels are not multiplied by this build's timings."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "daily-ray-trace_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes(S, v_int, v_shade, xyz=False):
@@ -80,9 +110,11 @@ def cpu_baseline(bundle_loader, width, height, depth, seconds_target=12.0):
 
 VALU_PEAK_GCYCLES = 1024 * 2.4  # vector-issue cycles available per ns: 256 CUs x 4 SIMDs at the 2.4 GHz peak shader clock
 FP64_PEAK_TFLOPS = 78.6         # 1024 SIMDs x 16 f64 lanes per clock x 2 (FMA) x 2.4 GHz (MI355X_MICROARCH.md: half the 157.3 TF f32 vector rate)
+FP64_PEAK_NO_FMA_TFLOPS = 39.3  # the same with one flop per lane and clock: the path is compiled -ffp-contract=off (the reference's
+                                # operation order is the contract), so a*b+c is two instructions and this is the peak it can reach
 
 
-def roofline(dominant, kernel_ms, launches, paths_per_launch, model, workload, xyz):
+def roofline(dominant, kernel_ms, launches, paths_per_launch, model, workload, xyz, profile_name="roofline.json"):
     """The `roofline` object of the JSON line, for the dominant kernel.
 
     This path has no dense contraction (no MFMA) and keeps its spectra in registers, so neither the matrix peak nor the HBM
@@ -95,15 +127,22 @@ def roofline(dominant, kernel_ms, launches, paths_per_launch, model, workload, x
     this design does not move those bytes, so they are never divided by time into a bandwidth."""
     avg_ms = {k: (kernel_ms[k] / launches if launches else 0.0) for k in kernel_ms}
     out = {"bound": "fp64_valu", "kernel": "drt_%s_kernel" % dominant, "achieved": None, "peak": round(VALU_PEAK_GCYCLES, 1),
-           "unit": "G SIMD-cycles/s of vector issue", "frac": None, "traffic": None, "hbm_measured_frac": None,
+           "unit": "G SIMD-cycles/s of vector issue", "frac": None,
+           "frac_is": "vector-issue occupancy: the share of SIMD cycles in which the kernel issues a vector instruction "
+                      "(SQ_ACTIVE_INST_VALU x 4 / cycles available) -- how busy the pipe is, NOT useful work / peak; "
+                      "useful f64 work against the peak is `fp64` beside it",
+           "traffic": None, "hbm_measured_frac": None,
            "launch": {"paths": paths_per_launch, "avg_ms": round(avg_ms[dominant], 4), "count": launches}}
     prof = None
-    ppath = os.path.join(REPO, "profiles", "roofline.json")
+    ppath = os.path.join(REPO, "profiles", profile_name)
+    stale = None
     if os.path.exists(ppath) and not xyz:
         try:
             pj = json.load(open(ppath))
             if pj.get("workload") == workload:
                 prof = pj
+                if pj.get("csrc_sha") != csrc_sha():
+                    stale = "profiles/%s was taken from kernel sources %s, this build is %s" % (profile_name, pj.get("csrc_sha"), csrc_sha())
         except Exception:
             prof = None
     if prof:
@@ -121,7 +160,8 @@ def roofline(dominant, kernel_ms, launches, paths_per_launch, model, workload, x
                 d["lane_efficiency"] = e["lane_efficiency"]
             if "f64_flops" in e:
                 tf = e["f64_flops"] * paths_per_launch / sec / 1e12
-                d["fp64"] = {"achieved": round(tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_PEAK_TFLOPS, 4)}
+                d["fp64"] = {"achieved": round(tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_PEAK_TFLOPS, 4),
+                             "peak_no_fma": FP64_PEAK_NO_FMA_TFLOPS, "frac_no_fma": round(tf / FP64_PEAK_NO_FMA_TFLOPS, 4)}
             if "hbm_bytes" in e:
                 d["hbm_bytes_per_launch"] = round(e["hbm_bytes"] * paths_per_launch)
                 d["hbm_GBs"] = round(e["hbm_bytes"] * paths_per_launch / sec / 1e9, 1)
@@ -131,7 +171,10 @@ def roofline(dominant, kernel_ms, launches, paths_per_launch, model, workload, x
         out.update({"achieved": dk.get("valu_busy_Gcycles_per_s"), "frac": dk.get("valu_busy_frac"),
                     "traffic": dk.get("hbm_bytes_per_launch"), "hbm_measured_frac": dk.get("hbm_measured_frac"),
                     "lane_efficiency": dk.get("lane_efficiency"), "fp64": dk.get("fp64"), "per_kernel": per_kernel,
-                    "counters_from": "profiles/roofline.json <- %s" % prof.get("source", "")})
+                    "counters_from": "profiles/%s <- %s" % (profile_name, prof.get("source", ""))})
+        if stale:
+            # per-path counters of another build times this build's timings would be a number about neither
+            out.update({"achieved": None, "frac": None, "stale_profile": stale})
     else:
         out["note"] = "no committed PMC profile matches this workload (profiles/roofline.json): vector-issue and HBM fractions not reported"
     out["algorithmic_model"] = {
@@ -143,12 +186,12 @@ def roofline(dominant, kernel_ms, launches, paths_per_launch, model, workload, x
     return out
 
 
-def oneshot_child(size, spp, depth):
+def oneshot_child(size, spp, depth, scene="cornell_plane_light.scn"):
     """Fresh process: the drop-in call itself -- drt_render_tile() with caller-owned host buffers, zero-filled as the reference's
     alloc() leaves them (DRT_FLAG_FILM_ZERO), film copied back to the host -- timed wall-clock, PCIe and context set-up included."""
     import numpy as np
     import pydrt
-    bundle = pydrt.load_scene(os.path.join(REPO, "scenes", "cornell_plane_light.scn"), size, size)
+    bundle = load_workload_scene(scene, size, size)
     pydrt.render_tile(bundle, pydrt.make_params(64, 64, spp=1, max_depth=depth, seed=1))  # HIP runtime and code object loaded
     runs = []
     for _ in range(2):
@@ -162,20 +205,24 @@ def oneshot_child(size, spp, depth):
     print(json.dumps({"oneshot": runs}), flush=True)
 
 
-def oneshot_leg(size, spp, depth):
+def oneshot_leg(size, spp, depth, scene="cornell_plane_light.scn"):
     """The same workload through the one-shot C-ABI call, in a child process of its own (a fresh HIP context, as a caller of the
     drop-in would have): value = the better of two calls."""
     import subprocess
-    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--oneshot-child", "--size", str(size), "--spp", str(spp), "--depth", str(depth)],
-                         capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--oneshot-child", "--size", str(size), "--spp", str(spp), "--depth", str(depth),
+                          "--scene", scene], capture_output=True, text=True, timeout=900)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if out.returncode != 0 or not lines:
         return {"error": (out.stderr or out.stdout)[-300:]}
     runs = json.loads(lines[-1])["oneshot"]
-    best = max(runs, key=lambda r: r["Mpaths_per_s"])
-    return {"value": best["Mpaths_per_s"], "unit": "Mpaths/s", "wall_ms": best["wall_ms"], "device_kernel_ms": best["device_kernel_ms"], "runs": runs,
+    # The reference's main() calls render_image() ONCE (src/win32_main.c:146), so the call a maintainer sees is the FIRST one of a
+    # process: `cold` (device memory the process touches for the first time is cleared by the driver, pages are faulted in) is the
+    # value; `warm` (the same call again in the same process) is beside it.
+    cold, warm = runs[0], runs[-1]
+    return {"value": cold["Mpaths_per_s"], "unit": "Mpaths/s", "wall_ms": cold["wall_ms"], "device_kernel_ms": cold["device_kernel_ms"],
+            "cold": cold, "warm": warm, "runs": runs,
             "what": "drt_render_tile(): host film buffers (zero-filled, DRT_FLAG_FILM_ZERO), context creation, kernels, film download over PCIe; "
-                    "fresh process; never the headline `value`"}
+                    "fresh process; value = the process's FIRST call (cold); never the headline `value`"}
 
 
 def self_launch(n):
@@ -213,9 +260,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--spp", type=int, default=256)
-    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS),
+                    help="which BASELINE config: config2 = the headline (configs[1], cornell_plane_light 1024^2 x 256 spp, depth 8); "
+                         "config3 = configs[2] (cornell_large_box 2048^2 x 1024 spp, depth 16, the one tiled over 8 GPUs); config4; config5")
+    ap.add_argument("--size", type=int, default=0, help="image width = height (0: the workload's)")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel (0: the workload's)")
+    ap.add_argument("--depth", type=int, default=0, help="max depth (0: the workload's)")
+    ap.add_argument("--scene", default="", help=argparse.SUPPRESS)
     ap.add_argument("--batch", type=int, default=0, help="samples per kernel pair (0 = library default)")
     ap.add_argument("--gather-blocks", type=int, default=0, help="row blocks per rank (0 = 1 at N=1, 4 at N>1)")
     ap.add_argument("--block-streams", type=int, default=1, help="HIP streams the row blocks are spread over (blocks on different streams overlap)")
@@ -230,8 +281,12 @@ def main():
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes needs dmabuf IPC on this driver
+    wl_scene, wl_size, wl_spp, wl_depth, wl_label = WORKLOADS[args.workload]
+    args.size = args.size or wl_size
+    args.spp = args.spp or wl_spp
+    args.depth = args.depth or wl_depth
     if args.oneshot_child:
-        return oneshot_child(args.size, args.spp, args.depth)
+        return oneshot_child(args.size, args.spp, args.depth, args.scene or wl_scene)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
     import torch
@@ -248,17 +303,25 @@ def main():
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    def die(stage, err):
+        """A failing rank fails the run, loudly: no fallback to another backend, no JSON line."""
+        sys.stderr.write("bench.py: rank %d of %d (GPU %d): %s failed with backend %r: %s: %s\n" % (rank, world, local_rank, stage, args.backend, type(err).__name__, err))
+        sys.stderr.flush()
+        os._exit(3)
+
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(args.backend, rank=rank, world_size=world)
+        except Exception as err:  # noqa: BLE001 -- whatever the backend raises, the run is over
+            die("init_process_group", err)
 
     W = H = args.size
-    scene_file = os.path.join(REPO, "scenes", "cornell_plane_light.scn")
-    bundle = pydrt.load_scene(scene_file, W, H)
+    bundle = load_workload_scene(wl_scene, W, H)
     S = bundle.S
     dev = torch.device("cuda", local_rank)
     n_tile = drt_dist.rank_rows(H, rank, world)[1] * W
@@ -353,29 +416,50 @@ def main():
         out["pool_peak_bytes"] = max(st.record_pool_peak * st.record_block_bytes for st in sts)
         return out
 
-    if world > 1:
-        # set up the communicator and its point-to-point connections (made lazily on first use) outside the timed region,
-        # whatever --warmup is: one gather of the same shape as a block's
-        blocks[0].gather_async(staging=staging)
-        finish_on_side(blocks[0])
-        stream.wait_stream(side)
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    st0 = all_stats()
-    gather_ms[0] = 0.0
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    st1 = all_stats()
+    try:
+        if world > 1:
+            # set up the communicator and its point-to-point connections (made lazily on first use) outside the timed region,
+            # whatever --warmup is: one gather of the same shape as a block's
+            blocks[0].gather_async(staging=staging)
+            finish_on_side(blocks[0])
+            stream.wait_stream(side)
+            torch.cuda.synchronize()
+    except Exception as err:  # noqa: BLE001
+        die("the first gather (communicator set-up)", err)
+    try:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        st0 = all_stats()
+        gather_ms[0] = 0.0
+        t_start = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        local_elapsed = time.perf_counter() - t_start  # this rank's own steps, before it waits for the others
+        barrier()
+        elapsed = time.perf_counter() - t_start
+        st1 = all_stats()
+    except Exception as err:  # noqa: BLE001
+        die("rendering / gathering", err)
     batch_spp = live[0].batch_spp()
     block_pixels = blocks[0].rows * W
+    per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if staging else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        try:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if staging else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            # every rank's own figures, per step: kernel time on its GPU (HIP events), wall time of its steps before the barrier,
+            # and how long it waited for gathers that rendering did not hide
+            mine = torch.tensor([(st1["trace_ms"] - st0["trace_ms"] + st1["shade_ms"] - st0["shade_ms"]) / args.steps,
+                                 local_elapsed * 1e3 / args.steps, gather_ms[0] / args.steps,
+                                 float(drt_dist.rank_rows(H, rank, world)[1])], dtype=torch.float64, device="cpu" if staging else dev)
+            everyone = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(everyone, mine)
+            per_rank = [[float(x) for x in e.cpu()] for e in everyone]
+        except Exception as err:  # noqa: BLE001
+            die("the timing reductions", err)
 
     # kernel time from HIP events recorded by the library on the launch stream (timed region only)
     paths_rank = st1["paths"] - st0["paths"]
@@ -394,18 +478,22 @@ def main():
         paths_per_launch_all = batch_spp * sum(fb.rows for fb in blocks) * W  # this rank's launches side by side (one context per row block)
         launches = max(1, round(paths_rank / max(paths_per_launch, 1)))
         kernel_ms = {"trace": trace_ms, "shade": shade_ms}
+        scene_stem = wl_scene.replace(".scn", "").replace("@", "").replace(":", "_")
         roof = roofline(dominant, kernel_ms, launches, paths_per_launch, model,
-                        "cornell_plane_light %dx%d depth %d" % (W, H, args.depth), xyz)
+                        "%s %dx%d depth %d" % (scene_stem, W, H, args.depth), xyz,
+                        "roofline.json" if args.workload == "config2" else "roofline_%s.json" % args.workload)
         roof.update({"kernel_ms_per_step": {"trace": round(trace_ms / args.steps, 3), "shade": round(shade_ms / args.steps, 3)},
                      "v_int": round(v_int, 4), "v_shade": round(v_shade, 4)})
         if st1["redone_launches"]:
             raise SystemExit("bench.py: %d launches ran out of record blocks and were rendered again: the timing is not the path's" % st1["redone_launches"])
         out = {
-            "metric": "Mpaths/s (pixels*spp/s) Cornell 1024^2 depth 8; achieved HBM GB/s % of peak" + (" [XYZ-only film: NOT the headline mode]" if xyz else ""),
+            "metric": "Mpaths/s (pixels*spp/s) Cornell 1024^2 depth 8; achieved HBM GB/s % of peak" + (" [XYZ-only film: NOT the headline mode]" if xyz else "") +
+                      ("" if args.workload == "config2" else " [workload %s: NOT the headline config]" % args.workload),
             "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "cornell_plane_light.scn %dx%d, %d spp, depth %d (BASELINE configs[1])" % (W, H, args.spp, args.depth),
+            "config": {"workload": "%s %dx%d, %d spp, depth %d (%s%s)" % (wl_scene, W, H, args.spp, args.depth, wl_label,
+                                                                             "" if (W, args.spp, args.depth) == (wl_size, wl_spp, wl_depth) else ", REDUCED from its stated size"),
                        "film": ("XYZ only (DRT_MODE_XYZ: 8 accumulators per pixel, no mean/variance)" if xyz else
                                 "full spectral (sum+filter, mean, variance x %d wavelengths)" % S),
                        "partition": ("whole frame on one GPU" if world == 1 and len(blocks) == 1 else
@@ -416,7 +504,19 @@ def main():
             "roofline": roof,
         }
         if world > 1:
-            out["gather_ms_per_step"] = round(gather_ms[0] / args.steps, 3)  # the part not hidden behind rendering
+            out["gather_ms_per_step"] = round(gather_ms[0] / args.steps, 3)  # the part not hidden behind rendering (rank 0)
+            k_ms = [r[0] for r in per_rank]
+            out["per_rank_ms"] = {"kernels": [round(x, 3) for x in k_ms], "wall": [round(r[1], 3) for r in per_rank],
+                                  "gather_wait": [round(r[2], 3) for r in per_rank], "rows": [int(r[3]) for r in per_rank],
+                                  "what": "per step and rank: trace + shade kernel time on the rank's GPU (HIP events), wall time of its own steps "
+                                          "(gathers and rank 0's frame assembly included), the part of the gathers rendering did not hide, image rows owned"}
+            out["load_imbalance"] = round(max(k_ms) / (sum(k_ms) / len(k_ms)), 4) if sum(k_ms) > 0 else None  # slowest rank's kernel time / the mean
+            # rank 0 holds the assembled frame and one receive buffer per row block beside its own share of the work
+            frame_b = sum(int(t.numel()) * 8 for t in blocks[0].image)
+            recv_b = sum(int(fb.recv.numel()) * 8 for fb in blocks if fb.recv is not None)
+            out["config"]["rank0_frame_GB"] = round(frame_b / 1e9, 2)
+            out["config"]["rank0_recv_buffers_GB"] = round(recv_b / 1e9, 2)
+            out["config"]["collective"] = "torch.distributed.gather, backend %s (nccl = RCCL over xGMI), one per row block, async behind the next block's kernels" % args.backend
         if args.checksum:
             # wrap-around int64 sum of the bit patterns: exact and independent of the order of pixels
             if world == 1:
@@ -424,15 +524,16 @@ def main():
                     fb.finish()
             torch.cuda.synchronize()
             out["frame_checksum"] = [int(t.view(torch.int64).sum().item()) for t in blocks[0].image]
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(lambda: pydrt.load_scene(scene_file, W, H), W, H, args.depth)
+        if not args.no_cpu_baseline:
+            # rank 0 only, after the timed region (the other ranks wait at the final barrier)
+            out["cpu_baseline"] = cpu_baseline(lambda: load_workload_scene(wl_scene, W, H), W, H, args.depth)
     for r in live:
         r.close()
     if rank == 0:
         if not args.no_oneshot and world == 1 and not xyz:
             del blocks, renderers, live
             torch.cuda.empty_cache()
-            out["oneshot"] = oneshot_leg(W, args.spp, args.depth)
+            out["oneshot"] = oneshot_leg(W, args.spp, args.depth, wl_scene)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

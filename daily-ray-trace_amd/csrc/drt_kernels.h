@@ -307,19 +307,32 @@ __device__ __forceinline__ double leaf_distance(const SceneView &sv, const BvhLe
  * (u = 2^-24): the conversions of o and 1/d, the product o * inv and the fused multiply-add together move a slab plane by at
  * most 2u |o| + 2u |lo - o| in position, i.e. < 4.6e-5 for coordinates within 64; the builder pads every stored box by
  * 2^-19 x (largest coordinate of the scene and the camera) on top of its f64 padding, more than twice that (see
- * BvhBuilder::build). A NaN (0 x inf on an axis the ray is parallel to) drops out of min / max: that slab then does not
- * constrain the interval, which errs on the accepting side. */
+ * BvhBuilder::build).
+ * An axis the ray is (nearly) parallel to: 1/d would be +-inf (or so large that lo * inv overflows), and then ONE of the two
+ * slab planes gives inf - inf = NaN while the other gives -+inf -- a box that straddles the origin's coordinate would be
+ * rejected. So |1/d| is capped at 2^100: the slab's interval becomes [(lo - o) 2^100, (hi - o) 2^100] instead of the true,
+ * still longer one. A hit inside the box lies at a distance t <= 4 E with o within the unpadded box on that axis, i.e.
+ * hi - o and o - lo >= 2^-19 E less the rounding above: the capped interval still contains t, so the box is still accepted,
+ * and an origin outside the slab still rejects it (both ends on one side of 0). Coordinates stay below 2^27 (E x 2^100 must
+ * not overflow; the builder refuses larger scenes). A NaN direction (total internal reflection, src/geometry.c:92-106) stays
+ * NaN and rejects every box, as it misses every surface in the reference. */
+#define BVH_INV_CAP 1.2676506e30f /* 2^100 */
 struct Ray32
 {
     float ix, iy, iz, nx, ny, nz; /* 1/d and -o/d */
     float ox, oy, oz, dx, dy, dz; /* o and d */
 };
+__device__ __forceinline__ float bvh_inv32(double d)
+{
+    const float i = __builtin_amdgcn_rcpf((float)d); /* v_rcp_f32: 1 ulp, inside the budget above */
+    return __builtin_fabsf(i) > BVH_INV_CAP ? __builtin_copysignf(BVH_INV_CAP, i) : i;
+}
 __device__ __forceinline__ Ray32 bvh_ray32(V3 o, V3 d)
 {
     Ray32 r;
-    r.ix = __builtin_amdgcn_rcpf((float)d.x); /* v_rcp_f32: 1 ulp, inside the budget above */
-    r.iy = __builtin_amdgcn_rcpf((float)d.y);
-    r.iz = __builtin_amdgcn_rcpf((float)d.z);
+    r.ix = bvh_inv32(d.x);
+    r.iy = bvh_inv32(d.y);
+    r.iz = bvh_inv32(d.z);
     r.nx = -((float)o.x * r.ix);
     r.ny = -((float)o.y * r.iy);
     r.nz = -((float)o.z * r.iz);
@@ -2130,6 +2143,7 @@ enum
     DRT_UNIT_FS_DIELECTRIC,     /* in: ir tr cos                           out: R                         src/bdsf.c:44-67       */
     DRT_UNIT_FS_CONDUCTOR,      /* in: ir tr te cos                        out: R                         src/bdsf.c:78-101      */
     DRT_UNIT_SEED_AND_DRAW,     /* in: path key (u64 bits)                 out: state (bits), first rng() src/rng.c:1-12, SURVEY 8a-R */
+    DRT_UNIT_BVH_BOX,           /* in: o[3] d[3] lo[3] hi[3] (box in f32 values) out: the f32 slab test's entry bound, or < 0 = box rejected (bvh_box_entry) */
     DRT_UNIT_COUNT
 };
 
@@ -2185,6 +2199,17 @@ __global__ void drt_unit_kernel(int func, const double *__restrict__ in, uint32_
             uint32_t draws = 0;
             o[0] = __longlong_as_double((long long)rs);
             o[1] = drt_rng(rs, draws);
+            break;
+        }
+        case DRT_UNIT_BVH_BOX:
+        {
+            BvhNode n;
+            for (int k = 0; k < 3; k += 1)
+            {
+                n.lo[0][k] = (float)a[6 + k];
+                n.hi[0][k] = (float)a[9 + k];
+            }
+            o[0] = (double)bvh_box_entry(n, 0, bvh_ray32(V(0), V(3)));
             break;
         }
         default: break;

@@ -21,6 +21,14 @@ static thread_local std::string g_last_error;
 
 #define DRT_DEFAULT_MAX_BATCH 256 /* samples per kernel pair when the caller leaves batch_spp = 0 */
 
+/* d_counters, in 8-byte words: [0, DRT_NUM_COUNTERS) the statistics of complete kernel pairs; then the WORK words of the pair in
+ * flight -- +0 trace queue, +1 shade queue, +2 bounce queue length, +3 spare, +4 pool cursor (zeroed before every trace launch),
+ * +5 overflow flag, +6 sequence number of the last complete pair, +7 peak of the pool cursor -- then, at DRT_PAIR_COUNTERS, the
+ * statistics of the pair in flight: the kernels count there, and drt_mark_pair_kernel adds them to the totals only when the pair
+ * was complete (a pair whose pool ran out is rendered again, and would be counted twice) */
+#define DRT_PAIR_COUNTERS (DRT_NUM_COUNTERS + 8)
+#define DRT_COUNTER_WORDS (DRT_PAIR_COUNTERS + DRT_NUM_COUNTERS)
+
 static int fail(int code, const char *fmt, ...)
 {
     char buf[512];
@@ -62,15 +70,14 @@ struct drt_context
     uint64_t  pool_blocks = 0;          /* blocks in d_records */
     uint32_t  worst_blocks_per_path = 0; /* what a path of max_depth vertices takes (table block included) */
     double    est_blocks_per_path = 0.0; /* measured on a sample of the tile when the context is created */
-    struct Batch { uint32_t first_sample, n_samples; uint64_t seq; uint32_t row0, rows; }; /* rows == 0: the whole tile */
+    struct Batch { uint32_t first_sample, n_samples; uint64_t seq; uint32_t row0, rows, hits_sample_offset, stride; }; /* rows == 0: the whole tile */
     std::vector<Batch> inflight;         /* kernel pairs enqueued since the last synchronisation (redone if the pool ran out) */
     uint64_t  next_seq = 1;
     uint64_t  redone_batches = 0, pool_peak = 0;
     int32_t  *d_hits = nullptr;
     uint64_t  hits_capacity = 0; /* in paths */
     uint32_t  hits_samples = 0;
-    unsigned long long *d_counters = nullptr; /* DRT_NUM_COUNTERS stats; per kernel pair: trace queue, shade queue, bounce queue length, spare, pool cursor;
-                                                 then overflow flag, sequence number of the last complete kernel pair, peak of the pool cursor */
+    unsigned long long *d_counters = nullptr; /* DRT_COUNTER_WORDS words: layout at DRT_PAIR_COUNTERS above */
     PrimaryHit *d_primary = nullptr;          /* BVH pipeline: closest hit of every path's camera ray (drt_bvh_kernels.h) */
     uint64_t   *d_queue = nullptr;            /* BVH pipeline: ids of the paths that go on after their first hit */
     bool        bvh_pipeline = false;
@@ -88,8 +95,11 @@ struct drt_context
     uint64_t n_pix = 0;
 
     std::vector<hipEvent_t> ev; /* triples: trace start, trace end / shade start, shade end */
+    std::vector<double> ev_paths; /* per triple: the paths of that kernel pair */
     size_t ev_used = 0;
     double trace_ms = 0.0, shade_ms = 0.0;
+    uint64_t timed_pairs = 0; /* per sample pass over the tile (src/daily_ray_trace.c:746-756): min, max, running mean over the pairs */
+    double min_sample_ms = 0.0, max_sample_ms = 0.0, avg_sample_ms = 0.0;
 };
 
 static size_t trace_lds_bytes(uint32_t n_surf, uint32_t n_lights, uint32_t n_mat)
@@ -529,6 +539,8 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene, double r
         bb.build(scene, reach);
         /* the traversal stacks hold BVH_STACK entries, one per level at most, and push unchecked */
         if (bb.max_depth > BVH_STACK) return fail(-2, "BVH of %zu surfaces is %d levels deep, the traversal stack holds %d", bb.prims.size(), bb.max_depth, BVH_STACK);
+        /* the f32 box test multiplies coordinates by 1/d capped at 2^100 (drt_kernels.h, bvh_inv32) */
+        if (!(bb.extent < 134217728.0)) return fail(-2, "scene or camera coordinates reach %g: the hierarchy's f32 box test holds up to 2^27", bb.extent);
         std::vector<BvhLeafPrim> leaf(std::max<size_t>(bb.order.size(), 1));
         memset(leaf.data(), 0, leaf.size() * sizeof(BvhLeafPrim));
         for (size_t k = 0; k < bb.order.size(); k += 1)
@@ -752,14 +764,16 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     HIP_TRY(hipMemsetAsync(ctx->d_pixels, 0, pixels_bytes(ctx), ctx->stream));
     if (ctx->d_avgs) HIP_TRY(hipMemsetAsync(ctx->d_avgs, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
     if (ctx->d_vars) HIP_TRY(hipMemsetAsync(ctx->d_vars, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
-    HIP_TRY(hipMalloc((void **)&ctx->d_counters, (DRT_NUM_COUNTERS + 8) * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 8) * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMalloc((void **)&ctx->d_counters, DRT_COUNTER_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, DRT_COUNTER_WORDS * sizeof(unsigned long long), ctx->stream));
 
     /* persistent trace grid: as many workgroups as the chip keeps resident */
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
     int per_cu = 0;
-    if (ctx->scene_in_lds)
+    if (ctx->scene_in_lds && ctx->trace_tail) /* the instantiation that will be launched: its registers and LDS decide the grid */
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, drt_trace_kernel<true, true>, TRACE_BLOCK, ctx->trace_lds));
+    else if (ctx->scene_in_lds)
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, drt_trace_kernel<true, false>, TRACE_BLOCK, ctx->trace_lds));
     if (per_cu < 1) per_cu = 1;
     if (const char *e = getenv("DRT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e)); /* tuning knob */
@@ -848,15 +862,16 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
         ctx->n_pix = keep_pix;
         if (rc) return rc;
         unsigned long long used = 0; /* blocks handed to paths (the cursor also counts the waves' part-used chunks) */
-        HIP_TRY(hipMemcpyAsync(&used, ctx->d_counters + 5, sizeof(used), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(&used, ctx->d_counters + DRT_PAIR_COUNTERS + 5, sizeof(used), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         ctx->est_blocks_per_path = (double)used / (double)n_sample;
         (void)hipFree(ctx->d_records); ctx->d_records = nullptr;
         (void)hipFree(ctx->d_headers); ctx->d_headers = nullptr;
         (void)hipFree(ctx->d_primary); ctx->d_primary = nullptr;
         (void)hipFree(ctx->d_queue); ctx->d_queue = nullptr;
-        HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 8) * sizeof(unsigned long long), ctx->stream)); /* the sample does not count */
+        HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, DRT_COUNTER_WORDS * sizeof(unsigned long long), ctx->stream)); /* the sample does not count */
         ctx->ev_used = 0;
+        ctx->ev_paths.clear();
     }
     /* blocks a launch of n paths is given: 1.3 x the expectation, 8 sigma of a sum of n on top (a path's block count has a
      * standard deviation below 2), never less than one sample per pixel in the worst case (what redo_batches launches) */
@@ -1005,17 +1020,34 @@ static int collect_timings(drt_context *ctx)
         HIP_TRY(hipEventElapsedTime(&b, ctx->ev[k + 1], ctx->ev[k + 2]));
         ctx->trace_ms += a;
         ctx->shade_ms += b;
+        const double paths = k / 3 < ctx->ev_paths.size() ? ctx->ev_paths[k / 3] : 0.0;
+        if (paths > 0.0)
+        {
+            const double t = ((double)a + (double)b) * (double)ctx->n_pix / paths; /* one sample of every tile pixel at this pair's rate */
+            if (ctx->timed_pairs == 0 || t < ctx->min_sample_ms) ctx->min_sample_ms = t;
+            if (ctx->timed_pairs == 0 || t > ctx->max_sample_ms) ctx->max_sample_ms = t;
+            ctx->timed_pairs += 1;
+            ctx->avg_sample_ms += (t - ctx->avg_sample_ms) / (double)ctx->timed_pairs;
+        }
     }
     ctx->ev_used = 0;
+    ctx->ev_paths.clear();
     return 0;
 }
 
 /* after a kernel pair: if the pool did not run out, this pair is the last complete one; the pool's high-water mark */
-__global__ void drt_mark_pair_kernel(unsigned long long *state, unsigned long long seq)
+__global__ void drt_mark_pair_kernel(unsigned long long *totals, unsigned long long seq)
 {
     /* state[0] pool cursor of this pair, [1] overflow flag, [2] last complete pair, [3] peak of the cursor */
-    if (*(const uint32_t *)(state + 1) == 0u) state[2] = seq;
+    unsigned long long *state = totals + DRT_NUM_COUNTERS + 4, *pair = totals + DRT_PAIR_COUNTERS;
+    const bool complete = *(const uint32_t *)(state + 1) == 0u;
+    if (complete) state[2] = seq;
     if (state[0] > state[3]) state[3] = state[0];
+    for (int k = 0; k < DRT_NUM_COUNTERS; k += 1)
+    {
+        if (complete) totals[k] += pair[k]; /* an incomplete pair is rendered again: its paths are counted then */
+        pair[k] = 0;
+    }
 }
 
 /* The trace stage of one kernel pair over samples [first_sample, first_sample + n) of every tile pixel: work queues and the
@@ -1067,17 +1099,17 @@ static int enqueue_trace(drt_context *ctx, uint32_t first_sample, uint32_t n, ui
         const uint64_t packets = (tp.n_paths + 63) / 64;
         const uint32_t pgrid = (uint32_t)std::min<uint64_t>((packets + PRIMARY_BLOCK / 64 - 1) / (PRIMARY_BLOCK / 64), (uint64_t)ctx->primary_grid_cap);
         hipLaunchKernelGGL(drt_primary_kernel, dim3(pgrid), dim3(PRIMARY_BLOCK), 0, ctx->stream, ctx->dsc, ctx->dcam, tp, ctx->d_headers,
-                           ctx->d_hits, ctx->d_counters, ctx->d_primary, ctx->d_queue, work + 2);
+                           ctx->d_hits, ctx->d_counters + DRT_PAIR_COUNTERS, ctx->d_primary, ctx->d_queue, work + 2);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(drt_bounce_kernel, dim3(grid), dim3(BOUNCE_BLOCK), 0, ctx->stream, ctx->dsc, ctx->dcam, tp, ctx->d_records,
-                           ctx->d_headers, ctx->d_hits, ctx->d_counters, work, ctx->d_primary, ctx->d_queue, work + 2);
+                           ctx->d_headers, ctx->d_hits, ctx->d_counters + DRT_PAIR_COUNTERS, work, ctx->d_primary, ctx->d_queue, work + 2);
     }
     else if (ctx->trace_tail && tp.tail_stage)
         hipLaunchKernelGGL((drt_trace_kernel<true, true>), dim3(grid), dim3(TRACE_BLOCK), ctx->trace_lds, ctx->stream, ctx->dsc,
-                           ctx->dcam, tp, ctx->d_records, ctx->d_headers, ctx->d_hits, ctx->d_counters, work);
+                           ctx->dcam, tp, ctx->d_records, ctx->d_headers, ctx->d_hits, ctx->d_counters + DRT_PAIR_COUNTERS, work);
     else
         hipLaunchKernelGGL((drt_trace_kernel<true, false>), dim3(grid), dim3(TRACE_BLOCK), ctx->trace_lds, ctx->stream, ctx->dsc,
-                           ctx->dcam, tp, ctx->d_records, ctx->d_headers, ctx->d_hits, ctx->d_counters, work);
+                           ctx->dcam, tp, ctx->d_records, ctx->d_headers, ctx->d_hits, ctx->d_counters + DRT_PAIR_COUNTERS, work);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1159,10 +1191,12 @@ static int enqueue_pair(drt_context *ctx, uint32_t first_sample, uint32_t n, uin
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     const uint64_t seq = ctx->next_seq++;
-    hipLaunchKernelGGL(drt_mark_pair_kernel, dim3(1), dim3(1), 0, ctx->stream, work + 4, (unsigned long long)seq);
+    hipLaunchKernelGGL(drt_mark_pair_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_counters, (unsigned long long)seq);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[2], ctx->stream));
-    ctx->inflight.push_back({first_sample, n, seq, row0, rows});
+    ctx->ev_paths.resize(ctx->ev_used / 3, 0.0);
+    ctx->ev_paths[ctx->ev_used / 3 - 1] = (double)n_pix * (double)n;
+    ctx->inflight.push_back({first_sample, n, seq, row0, rows, hits_sample_offset, stride});
     return 0;
 }
 
@@ -1183,9 +1217,8 @@ static int redo_batches(drt_context *ctx, uint64_t last_good_seq)
         ctx->redone_batches += 1;
         for (uint32_t done = 0; done < b.n_samples; done += safe)
         {
-            /* (hit logging, when on, is indexed by sample offset within the caller's drt_render call: the offsets of a redone
-             *  batch are not known here, and parity tests that log hits never run with an undersized pool) */
-            int rc = enqueue_pair(ctx, b.first_sample + done, std::min(safe, b.n_samples - done), done, b.row0, b.rows);
+            /* (the hit log is indexed by sample offset within the caller's drt_render call: the batch remembers its own) */
+            int rc = enqueue_pair(ctx, b.first_sample + done, std::min(safe, b.n_samples - done), b.hits_sample_offset + done, b.row0, b.rows);
             if (rc) return rc;
         }
     }
@@ -1302,9 +1335,11 @@ extern "C" int drt_reset_film(drt_context *ctx)
     HIP_TRY(hipMemsetAsync(ctx->d_pixels, 0, pixels_bytes(ctx), ctx->stream));
     if (ctx->d_avgs) HIP_TRY(hipMemsetAsync(ctx->d_avgs, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
     if (ctx->d_vars) HIP_TRY(hipMemsetAsync(ctx->d_vars, 0, (size_t)ctx->n_pix * S * 8, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, (DRT_NUM_COUNTERS + 8) * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, DRT_COUNTER_WORDS * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->trace_ms = ctx->shade_ms = 0.0;
+    ctx->timed_pairs = 0;
+    ctx->min_sample_ms = ctx->max_sample_ms = ctx->avg_sample_ms = 0.0;
     return 0;
 }
 
@@ -1347,6 +1382,10 @@ extern "C" int drt_read_xyz(drt_context *ctx, double *xyz)
 {
     if (!ctx || !xyz) return fail(-1, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
+    /* first the film itself: drt_synchronize is where a record pool that ran out is noticed and those samples are rendered again --
+     * a conversion enqueued before it would read the incomplete film */
+    int rc = drt_synchronize(ctx);
+    if (rc) return rc;
     if (!ctx->d_xyz) HIP_TRY(hipMalloc((void **)&ctx->d_xyz, (size_t)ctx->n_pix * 3 * 8));
     uint32_t grid = (uint32_t)((ctx->n_pix + 255) / 256);
     if (ctx->xyz_mode)
@@ -1356,8 +1395,7 @@ extern "C" int drt_read_xyz(drt_context *ctx, double *xyz)
         hipLaunchKernelGGL(drt_film_xyz_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->dsc, ctx->cmf_rw, ctx->cmf_x, ctx->cmf_y,
                            ctx->cmf_z, ctx->interval, ctx->n_pix, ctx->d_pixels, ctx->d_xyz);
     HIP_TRY(hipGetLastError());
-    int rc = drt_synchronize(ctx);
-    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(xyz, ctx->d_xyz, (size_t)ctx->n_pix * 3 * 8, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -1368,13 +1406,16 @@ static int film_to_bgra(drt_context *ctx, int which)
     if (which < 0 || which > 2) return fail(-1, "which = %d: 0 sum, 1 mean, 2 variance", which);
     if (ctx->xyz_mode) return fail(-4, "the XYZ film keeps no spectra: render in DRT_MODE_SPECTRAL for .bmp pixels");
     HIP_TRY(hipSetDevice(ctx->device));
+    int rc = drt_synchronize(ctx); /* the complete film first (see drt_read_xyz) */
+    if (rc) return rc;
     if (!ctx->d_bgra) HIP_TRY(hipMalloc((void **)&ctx->d_bgra, (size_t)ctx->n_pix * 4));
     const double *film = which == 0 ? ctx->d_pixels : which == 1 ? ctx->d_avgs : ctx->d_vars;
     uint32_t grid = (uint32_t)((ctx->n_pix + 255) / 256);
     hipLaunchKernelGGL(drt_film_bgra_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->dsc, ctx->cmf_rw, ctx->cmf_x, ctx->cmf_y,
                        ctx->cmf_z, ctx->interval, ctx->n_pix, film, which, ctx->d_bgra);
     HIP_TRY(hipGetLastError());
-    return drt_synchronize(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
 }
 
 extern "C" int drt_read_bgra(drt_context *ctx, int which, uint8_t *bgra)
@@ -1417,6 +1458,11 @@ extern "C" int drt_get_stats(drt_context *ctx, drt_stats *out)
     out->record_pool_peak = ctx->pool_peak;
     out->record_block_bytes = ctx->block_words * 8;
     out->redone_launches = (uint32_t)ctx->redone_batches;
+    out->launches = (uint32_t)std::min<uint64_t>(ctx->timed_pairs, 0xFFFFFFFFull);
+    out->path_flags = (ctx->bvh_pipeline ? DRT_PATH_BVH : 0u) | ((ctx->trace_tail && ctx->d_tail_stage) ? DRT_PATH_TRACE_TAIL : 0u);
+    out->min_sample_ms = ctx->min_sample_ms;
+    out->max_sample_ms = ctx->max_sample_ms;
+    out->avg_sample_ms = ctx->avg_sample_ms;
     return 0;
 }
 
@@ -1693,6 +1739,16 @@ extern "C" int drt_group_get_stats(drt_group *g, drt_stats *out)
         out->trace_ms = std::max(out->trace_ms, st.trace_ms);
         out->shade_ms = std::max(out->shade_ms, st.shade_ms);
         out->total_ms = std::max(out->total_ms, st.total_ms);
+        out->record_pool_blocks += st.record_pool_blocks; /* all the pools together; the fullest any of them has been */
+        out->record_pool_peak = std::max(out->record_pool_peak, st.record_pool_peak);
+        out->record_block_bytes = st.record_block_bytes;
+        out->redone_launches += st.redone_launches;
+        /* the devices run side by side: a sample pass over the whole tile takes as long as the slowest device's share */
+        out->launches += st.launches;
+        out->path_flags |= st.path_flags;
+        out->min_sample_ms = std::max(out->min_sample_ms, st.min_sample_ms);
+        out->max_sample_ms = std::max(out->max_sample_ms, st.max_sample_ms);
+        out->avg_sample_ms = std::max(out->avg_sample_ms, st.avg_sample_ms);
     }
     return 0;
 }
@@ -1756,8 +1812,8 @@ extern "C" int drt_selftest_unit(int device, int func, const double *in, uint32_
     if (func < 0 || func >= DRT_UNIT_COUNT) return fail(-1, "unknown unit function %d", func);
     if (!in || !out || in_stride == 0 || out_stride == 0) return fail(-1, "null argument");
     /* what each function reads and writes per record: a caller with narrower records would make the kernel read past its buffers */
-    static const uint32_t need_in[DRT_UNIT_COUNT] = {10, 18, 6, 8, 6, 1, 1, 7, 10, 3, 4, 1};
-    static const uint32_t need_out[DRT_UNIT_COUNT] = {1, 1, 3, 3, 9, 4, 4, 1, 1, 1, 1, 2};
+    static const uint32_t need_in[DRT_UNIT_COUNT] = {10, 18, 6, 8, 6, 1, 1, 7, 10, 3, 4, 1, 12};
+    static const uint32_t need_out[DRT_UNIT_COUNT] = {1, 1, 3, 3, 9, 4, 4, 1, 1, 1, 1, 2, 1};
     if (in_stride < need_in[func] || out_stride < need_out[func])
         return fail(-1, "unit function %d needs %u doubles in and %u out per record", func, need_in[func], need_out[func]);
     if (n == 0) return 0;

@@ -66,8 +66,11 @@ class FilmGather:
     A block covers the row indices j in [j0, j0 + block_rows) on every rank (fewer on ranks that run out of rows).
     Rendering block b+1 while block b's gather is in flight (gather_async) hides the transfer behind compute."""
 
-    def __init__(self, height, width, S, rank, world, device, dst=0, j0=0, block_rows=None, image=None, channels=None):
+    def __init__(self, height, width, S, rank, world, device, dst=0, j0=0, block_rows=None, image=None, channels=None, always_collective=False):
         self.height, self.width, self.S, self.rank, self.world, self.dst = height, width, S, rank, world, dst
+        # always_collective: a world of one still goes through torch.distributed.gather (the 1-rank RCCL test: the library, the f64
+        # gather and the process's IPC settings are exercised on a one-GPU box); otherwise one rank just copies its rows into the frame
+        self.collective = world > 1 or always_collective
         self.j0 = j0
         self.block_rows = max_tile_rows(height, world) if block_rows is None else block_rows
         self.rows = self.rows_of(rank)
@@ -76,7 +79,7 @@ class FilmGather:
         n_max = self.block_rows * width
         self.offsets = [n_max * sum(self.channels[:i]) for i in range(len(self.channels))]
         self.flat = torch.zeros(n_max * sum(self.channels), dtype=torch.float64, device=device)
-        self.recv = torch.empty((world, self.flat.numel()), dtype=torch.float64, device=device) if (rank == dst and world > 1) else None
+        self.recv = torch.empty((world, self.flat.numel()), dtype=torch.float64, device=device) if (rank == dst and self.collective) else None
         if rank == dst:
             self.image = image if image is not None else [torch.empty((height, width, c), dtype=torch.float64, device=device) for c in self.channels]
         else:
@@ -103,7 +106,7 @@ class FilmGather:
 
     def gather_async(self, group=None, staging=False):
         """Start the block's gather (one collective). finish() completes it and places the rows on dst."""
-        if self.world == 1:
+        if not self.collective:
             return
         send = self.flat.cpu() if staging else self.flat
         if self.rank == self.dst:
@@ -115,7 +118,7 @@ class FilmGather:
 
     def finish(self):
         """Wait for the gather, then (dst only) de-interleave the block's rows into the frame. Returns the frame buffers on dst."""
-        if self.world == 1:
+        if not self.collective:
             for i in range(len(self.channels)):
                 self.image[i][self.j0: self.j0 + self.rows] = self.region(i).view(self.rows, self.width, self.channels[i])
             return self.image

@@ -152,8 +152,13 @@ int render_image_ex(config_arguments *config, const drt_host_options *opt, drt_s
     }
     if (!(opt && opt->quiet))
     {
-        printf("Total render time: %fms (device %fms: trace %fms, shade+film %fms)\n", t1 - t0, stats.total_ms,
-               stats.trace_ms, stats.shade_ms);
+        /* the reference's report, src/daily_ray_trace.c:753-756; a "sample" is one sample pass over the image at the rate of one
+         * kernel pair (drt_stats, include/drt_hip.h) */
+        printf("Min sample time: %fms\n", stats.min_sample_ms);
+        printf("Max sample time: %fms\n", stats.max_sample_ms);
+        printf("Avg sample time: %fms\n", stats.avg_sample_ms);
+        printf("Total render time: %fms (device %fms: trace %fms, shade+film %fms, %u kernel pairs)\n", t1 - t0, stats.total_ms,
+               stats.trace_ms, stats.shade_ms, stats.launches);
         printf("Paths: %llu  closest-hit scans/path: %.3f  shaded vertices/path: %.3f  Mpaths/s (device): %.2f\n",
                (unsigned long long)stats.paths, (f64)stats.closest_hit_scans / (f64)stats.paths,
                (f64)stats.shaded_vertices / (f64)stats.paths, (f64)stats.paths / (stats.total_ms * 1e3));

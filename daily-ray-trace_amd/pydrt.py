@@ -21,6 +21,7 @@ MODE_SPECTRAL, MODE_XYZ = 0, 1
 FLAG_RECORD_HITS = 1
 BATCH_RESIDENT = 0xFFFFFFFF  # make_params(batch_spp=...): launches sized for a context kept across frames
 FLAG_FILM_ZERO = 2
+PATH_BVH, PATH_TRACE_TAIL = 1, 2  # Stats.path_flags
 
 # names and order of include/bdsf_list.h
 BDSF_NAMES = ["bp_diffuse_bdsf", "bp_glossy_bdsf", "mirror_bdsf", "fs_conductor_bdsf",
@@ -72,7 +73,9 @@ class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("closest_hit_scans", C.c_uint64), ("shaded_vertices", C.c_uint64),
                 ("shadow_scans", C.c_uint64), ("rng_draws", C.c_uint64), ("trace_ms", C.c_double),
                 ("shade_ms", C.c_double), ("total_ms", C.c_double), ("record_pool_blocks", C.c_uint64),
-                ("record_pool_peak", C.c_uint64), ("record_block_bytes", C.c_uint32), ("redone_launches", C.c_uint32)]
+                ("record_pool_peak", C.c_uint64), ("record_block_bytes", C.c_uint32), ("redone_launches", C.c_uint32),
+                ("launches", C.c_uint32), ("path_flags", C.c_uint32), ("min_sample_ms", C.c_double), ("max_sample_ms", C.c_double),
+                ("avg_sample_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -510,10 +513,10 @@ def selftest_arith(op, a, b=None, device=0):
 
 
 (UNIT_LINE_SPHERE, UNIT_LINE_PLANE, UNIT_REFLECT, UNIT_TRANSMIT, UNIT_ROTATION_BETWEEN, UNIT_SAMPLE_SPHERE, UNIT_SAMPLE_DISC,
- UNIT_GGX, UNIT_GGX_ATT, UNIT_FS_DIELECTRIC, UNIT_FS_CONDUCTOR, UNIT_SEED_AND_DRAW) = range(12)
+ UNIT_GGX, UNIT_GGX_ATT, UNIT_FS_DIELECTRIC, UNIT_FS_CONDUCTOR, UNIT_SEED_AND_DRAW, UNIT_BVH_BOX) = range(13)
 _UNIT_OUT = {UNIT_LINE_SPHERE: 1, UNIT_LINE_PLANE: 1, UNIT_REFLECT: 3, UNIT_TRANSMIT: 3, UNIT_ROTATION_BETWEEN: 9,
              UNIT_SAMPLE_SPHERE: 4, UNIT_SAMPLE_DISC: 4, UNIT_GGX: 1, UNIT_GGX_ATT: 1, UNIT_FS_DIELECTRIC: 1, UNIT_FS_CONDUCTOR: 1,
-             UNIT_SEED_AND_DRAW: 2}
+             UNIT_SEED_AND_DRAW: 2, UNIT_BVH_BOX: 1}
 
 
 def bvh_stats(bundle):

@@ -196,7 +196,19 @@ typedef struct drt_stats
     uint64_t record_pool_peak;
     uint32_t record_block_bytes;
     uint32_t redone_launches;
+    /* the reference's per-pass report (min / max / avg time of one sample pass over the image, src/daily_ray_trace.c:746-756): a
+     * kernel pair renders several samples of every pixel it covers, so a pair's HIP-event time is scaled to one sample of the
+     * whole tile -- ms x tile pixels / (pixels x samples of the pair) -- and min / max / avg run over the pairs */
+    uint32_t launches;   /* kernel pairs timed */
+    uint32_t path_flags; /* which kernels this context runs: DRT_PATH_* (a group: the devices' flags or'ed) */
+    double   min_sample_ms, max_sample_ms, avg_sample_ms;
 } drt_stats;
+
+enum
+{
+    DRT_PATH_BVH        = 1u, /* the scene is behind the bounding-volume hierarchy: drt_primary_kernel + drt_bounce_kernel trace it */
+    DRT_PATH_TRACE_TAIL = 2u  /* the trace kernel carries every path's tail wavelengths (all-plastic scenes); the shade kernel's tail pass only updates the film */
+};
 
 typedef struct drt_context drt_context;
 
@@ -301,7 +313,9 @@ int drt_selftest_arith(int device, int op, const double *a, const double *b, dou
  *   8 ggx_att                   src/bdsf.c:22-42         in v[3] sn[3] mn[3] roughness       out D * G1
  *   9 fs_dielectric_reflectance src/bdsf.c:44-67         in ir tr cos (one wavelength)       out R
  *  10 fs_conductor_reflectance  src/bdsf.c:78-101        in ir tr te cos (one wavelength)    out R
- *  11 seed_rng + rng            src/rng.c:1-12 (8a-R)    in path key (u64 bits)              out state (u64 bits), first rng() */
+ *  11 seed_rng + rng            src/rng.c:1-12 (8a-R)    in path key (u64 bits)              out state (u64 bits), first rng()
+ *  12 the hierarchy's f32 box test (prunes the scan of src/daily_ray_trace.c:340-364; no reference counterpart)
+ *                                                          in o[3] d[3] lo[3] hi[3]            out lower bound of the entry distance, < 0: rejected */
 int drt_selftest_unit(int device, int func, const double *in, uint32_t in_stride, double *out, uint32_t out_stride, uint64_t n);
 
 #ifdef __cplusplus

@@ -1,6 +1,6 @@
 """Generate tests/golden/*.npz from the REAL reference path (oracle/_ref/libdrt_ref.so).
 
-Run in a container where /root/reference exists:  make -C oracle ref && python oracle/make_golden.py
+Run in a container where /root/reference exists:  make -C oracle ref && python oracle/make_golden.py [render case ...]
 The fixtures are data only (inputs + the reference's outputs); they let the oracle be checked on
 machines where the reference cannot be built (the GPU box). Every array is float64/int32/uint64,
 loaded with numpy.load(allow_pickle=False).
@@ -215,8 +215,10 @@ def gen_bdsf(R, bundle):
                         state_after=state_after, all_dirs=all_dirs, all_pdfs=all_pdfs, direct=direct, direct_state=direct_state)
 
 
-def gen_renders(R):
-    for name in cases.RENDER_CASES:
+def gen_renders(R, only=None):
+    for name in list(cases.RENDER_CASES) + list(cases.NAN_CASES):
+        if only and name not in only:
+            continue
         bundle, params = cases.load_case(name)
         px, av, va = O.ref_render_tile(bundle, params)
         hits, spec_replay, spec_real = O.ref_trace_hits(bundle, params) if bundle.camera.aperture_radius == 0.0 else (None, None, None)
@@ -228,7 +230,7 @@ def gen_renders(R):
         for i in range(px.shape[0]):
             tmp[:] = px[i, :S] / px[i, S]
             R.ref_spectrum_to_xyz(p(tmp), p(xyz[i]))
-        full = name in ("plane_light_16",)
+        full = name in ("plane_light_16",) or name in cases.NAN_CASES
         data = dict(xyz=xyz, pix_sum=px[:, :S].sum(axis=1), avg_sum=av.sum(axis=1), var_sum=va.sum(axis=1), filter=px[:, S],
                     pix_sample=px[:: max(1, px.shape[0] // 16)], avg_sample=av[:: max(1, px.shape[0] // 16)],
                     var_sample=va[:: max(1, px.shape[0] // 16)])
@@ -245,6 +247,9 @@ def main():
     R = O.ref_lib()
     bundle = pydrt.load_scene(cases.scene_path("cornell_plane_light.scn"), 64, 64)
     R.ref_set_scene(C.byref(bundle.scene))
+    if len(sys.argv) > 1:  # python oracle/make_golden.py <render case> ...: only those fixtures
+        gen_renders(R, only=set(sys.argv[1:]))
+        return
     gen_geometry(R)
     gen_sampling(R)
     gen_spectral(R, bundle)

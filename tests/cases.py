@@ -34,12 +34,22 @@ RENDER_CASES = {
     "grid_4nm": ("cornell_plane_light.scn", 20, 20, 3, 6, 8, pydrt.FILM_SAMPLE_RANDOM, (380.0, 720.0, 4.0)),
     "grid_2p5nm": ("cornell_plane_light.scn", 20, 20, 3, 6, 8, pydrt.FILM_SAMPLE_RANDOM, (380.0, 720.0, 2.5)),
     "spheres_1500": ("@spheres:1500", 32, 32, 2, 6, 9, pydrt.FILM_SAMPLE_RANDOM),  # config 5 generator, reduced
+    # the two shipped scenes without an enclosing box (legacy syntax): a plastic sphere under a point light, 63 % of the camera rays escape
+    "first_scene": ("first_scene.scn", 32, 32, 4, 4, 1, pydrt.FILM_SAMPLE_RANDOM),
+}
+
+# example_scene.scn gives its camera no fov / fdepth / flength: init_camera (src/daily_ray_trace.c:49-77) then divides 0 by 0, every
+# camera ray is NaN, misses every surface and leaves NaN x 0 in the film -- what the reference's arithmetic does with that input is
+# the expected output here too: NaN for NaN, compared with fuzz_scenes.same()
+NAN_CASES = {
+    "example_scene": ("example_scene.scn", 16, 16, 3, 4, 1, pydrt.FILM_SAMPLE_RANDOM),
 }
 
 
 def load_case(name):
-    scene, w, h, spp, depth, seed, scheme = RENDER_CASES[name][:7]
-    grid = RENDER_CASES[name][7] if len(RENDER_CASES[name]) > 7 else (380.0, 720.0, 5.0)
+    case = RENDER_CASES[name] if name in RENDER_CASES else NAN_CASES[name]
+    scene, w, h, spp, depth, seed, scheme = case[:7]
+    grid = case[7] if len(case) > 7 else (380.0, 720.0, 5.0)
     if scene.startswith("@spheres:"):
         bundle = pydrt.synthetic_sphere_scene(int(scene.split(":")[1]), w, h)
     else:

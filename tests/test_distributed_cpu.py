@@ -104,6 +104,33 @@ def test_row_cyclic_tiles_gather_to_the_full_frame(tmp_path, world, height):
     assert np.array_equal(got["va"].reshape(-1, S), va)
 
 
+def _solo_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    sys.path.insert(0, os.path.join(cases.REPO, "daily-ray-trace_amd"))
+    import drt_dist
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    S, H, W = 5, 7, 4
+    fg = drt_dist.FilmGather(H, W, S, 0, 1, torch.device("cpu"), always_collective=True)
+    assert fg.collective and fg.recv is not None
+    want = []
+    for i in range(3):
+        t = torch.arange(fg.region(i).numel(), dtype=torch.float64).reshape(fg.region(i).shape) + 100.0 * i
+        fg.region(i).copy_(t)
+        want.append(t.reshape(H, W, -1))
+    fg.gather_async()
+    img = fg.finish()
+    assert all(torch.equal(a, b) for a, b in zip(img, want))
+    plain = drt_dist.FilmGather(H, W, S, 0, 1, torch.device("cpu"))
+    assert not plain.collective and plain.recv is None
+    dist.destroy_process_group()
+
+
+def test_world_of_one_can_still_go_through_the_collective():
+    """FilmGather(always_collective=True): a single rank runs the very gather the N > 1 path runs (what the 1-rank RCCL test on
+    the GPU box uses); by default a world of one just copies its rows into the frame."""
+    mp.spawn(_solo_worker, args=(1, _free_port()), nprocs=1, join=True)
+
+
 def test_rank_rows_cover_every_row_once():
     import drt_dist
     for height in (1, 7, 8, 1024, 2047):

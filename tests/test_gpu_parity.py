@@ -405,6 +405,10 @@ def test_record_pool_that_runs_out_is_rendered_again_not_wrong(monkeypatch):
     st1 = r.stats()
     assert st1.redone_launches >= 2 and st1.record_pool_blocks < st0.record_pool_blocks
     assert np.array_equal(px0, px1) and np.array_equal(av0, av1) and np.array_equal(va0, va1)
+    # a launch that ran out is counted when it is rendered again, not twice (the kernels count per pair; a pair's counts join
+    # the totals only when it was complete)
+    assert (st1.paths, st1.closest_hit_scans, st1.shaded_vertices, st1.shadow_scans, st1.rng_draws) == \
+           (st0.paths, st0.closest_hit_scans, st0.shaded_vertices, st0.shadow_scans, st0.rng_draws)
     # and the context goes on working: more samples on top, against a fresh run of all of them
     r.render(30, 5)
     px2, _, va2 = r.read_film()
@@ -741,6 +745,26 @@ def test_bench_two_rank_rehearsal_assembles_the_same_frame():
     three = last_json([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
                        "--master-port", "29534", bench, "--gpus", "3", "--backend", "gloo", "--share-device"] + common)
     assert three["n_gpus"] == 3 and three["frame_checksum"] == one100["frame_checksum"]
+    # what the first 8-GPU run will be read by: per-rank kernel / wall / gather-wait times, rows owned, the load imbalance, and
+    # rank 0's memory for the assembled frame and the receive buffers -- present and sane in the rehearsal
+    pr = three["per_rank_ms"]
+    assert [len(pr[k]) for k in ("kernels", "wall", "gather_wait", "rows")] == [3, 3, 3, 3] and pr["rows"] == [34, 33, 33]
+    assert all(x > 0 for x in pr["kernels"]) and all(w >= k * 0.5 for w, k in zip(pr["wall"], pr["kernels"]))
+    assert 1.0 <= three["load_imbalance"] < 3.0 and three["gather_ms_per_step"] >= 0.0
+    assert three["config"]["rank0_frame_GB"] > 0 and three["config"]["rank0_recv_buffers_GB"] > 0 and "gloo" in three["config"]["collective"]
+    # BASELINE configs[2] (cornell_large_box 2048^2 x 1024 spp, depth 16, tiled over the ranks) through the same code at a reduced
+    # size: two ranks assemble the single-process frame; the line names the config, says it is reduced and is not the headline's;
+    # and the CPU baseline is reported at N > 1 too (rank 0, after the timed region)
+    c3 = ["--workload", "config3", "--size", "128", "--spp", "8", "--steps", "1", "--warmup", "0", "--no-oneshot", "--checksum"]
+    one3 = last_json([sys.executable, bench, "--no-cpu-baseline"] + c3)
+    two3 = last_json([sys.executable, bench, "--gpus", "2", "--backend", "gloo", "--share-device"] + c3)
+    assert two3["frame_checksum"] == one3["frame_checksum"] and two3["config"]["paths_per_step"] == 128 * 128 * 8
+    assert "cornell_large_box.scn 128x128, 8 spp, depth 16" in two3["config"]["workload"] and "REDUCED" in two3["config"]["workload"]
+    assert "NOT the headline config" in two3["metric"] and two3["cpu_baseline"]["value"] > 0 and two3["cpu_baseline"]["cores"] == 1
+    # a backend that cannot start is a failed run with the rank and the reason on stderr, not a silent fall-back
+    bad = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "no_such_backend", "--share-device", "--size", "16", "--spp", "1",
+                          "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-oneshot"], env=env, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "init_process_group failed" in bad.stderr and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
 
 
 def test_drt_render_program_checkpoint_and_resume(tmp_path):
@@ -846,3 +870,351 @@ escape_material
     assert np.array_equal(hits, ohits) and cases.rel_err(px, opx) <= FILM_TOL and cases.rel_err(va, ova) <= FILM_TOL
     bad = pydrt.make_params(37, 23, spp=1, max_depth=2, x0=10, tile_w=30)  # tile runs off the image
     assert not pydrt.hip_lib().drt_create(C.byref(b2.scene), C.byref(b2.camera), C.byref(bad))
+
+
+# ---- round 3 ---------------------------------------------------------------------------------------------------------------
+
+def _render_all(bundle, p, record_hits=True):
+    """film, hits, XYZ and statistics of one context (like hip_render, with the caller's params untouched but for the hit flag)"""
+    q = pydrt.make_params(int(p.width), int(p.height), spp=int(p.spp), max_depth=int(p.max_depth), seed=int(p.seed), x0=int(p.x0), y0=int(p.y0),
+                          tile_w=int(p.tile_w), tile_h=int(p.tile_h), row_stride=int(p.row_stride), first_sample=int(p.first_sample),
+                          pixel_scheme=int(p.pixel_scheme), mode=int(p.mode), batch_spp=int(p.batch_spp),
+                          flags=pydrt.FLAG_RECORD_HITS if record_hits else 0)
+    r = pydrt.Renderer(bundle, q)
+    r.render()
+    film = (r.read_xyz_film(),) if int(p.mode) == pydrt.MODE_XYZ else r.read_film()
+    hits = r.read_hit_indices(int(q.spp)) if record_hits else None
+    xyz = r.read_xyz()
+    st = r.stats()
+    r.close()
+    return film, hits, xyz, st
+
+
+def _counts(st):
+    return (st.paths, st.closest_hit_scans, st.shaded_vertices, st.shadow_scans, st.rng_draws)
+
+
+# wavelength grids whose tail (S mod 64) is 5, 1, 6 and 8 wide -- the widths drt_trace_kernel<true, true> accepts run from 1 to 8;
+# every grid brackets 630 nm
+TAIL_GRIDS = {69: (380.0, 720.0, 5.0), 65: (380.0, 700.0, 5.0), 70: (400.0, 676.0, 4.0), 72: (400.0, 684.0, 4.0)}
+
+
+@pytest.mark.parametrize("scene,size,spp,depth", [("cornell_large_box.scn", 24, 3, 16), ("cornell_downward.scn", 20, 3, 6), ("first_scene.scn", 20, 3, 4)])
+@pytest.mark.parametrize("S", list(TAIL_GRIDS))
+def test_tail_wavelengths_in_the_trace_kernel_equal_the_tail_pass(scene, size, spp, depth, S, monkeypatch):
+    """All-plastic scenes are traced by drt_trace_kernel<true, true>, which carries every path's tail wavelengths itself
+    (Stats.path_flags says so); DRT_TRACE_TAIL=0 sends the same scene through the general kernel and the shade kernel's tail
+    pass. Film, hit indices, XYZ and statistics must be the same BIT FOR BIT, in the spectral and the XYZ film, for every
+    tail width, and both must be the oracle's. (cornell_downward has the mirror, first_scene the point light and no box.)"""
+    grid = TAIL_GRIDS[S]
+    bundle = pydrt.load_scene(cases.scene_path(scene), size, size, min_wl=grid[0], max_wl=grid[1], wl_interval=grid[2])
+    assert bundle.S == S
+    for mode in (pydrt.MODE_SPECTRAL, pydrt.MODE_XYZ):
+        p = pydrt.make_params(size, size, spp=spp, max_depth=depth, seed=5, mode=mode, batch_spp=2)
+        monkeypatch.delenv("DRT_TRACE_TAIL", raising=False)
+        a = _render_all(bundle, p)
+        monkeypatch.setenv("DRT_TRACE_TAIL", "0")
+        b = _render_all(bundle, p)
+        monkeypatch.delenv("DRT_TRACE_TAIL")
+        assert a[3].path_flags & pydrt.PATH_TRACE_TAIL and not (b[3].path_flags & pydrt.PATH_TRACE_TAIL)
+        assert all(np.array_equal(x, y) for x, y in zip(a[0], b[0])), (scene, S, mode)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and _counts(a[3]) == _counts(b[3])
+        if mode == pydrt.MODE_SPECTRAL:
+            opx, oav, ova, ohits, ost = O.oracle_render_tile(bundle, p, want_hits=True, math_mode=O.MATH_DEVICE)
+            assert np.array_equal(a[1], ohits) and _counts(a[3]) == _counts(ost)
+            assert cases.rel_err(a[0][0], opx) <= FILM_TOL and cases.rel_err(a[0][1], oav) <= FILM_TOL and cases.rel_err(a[0][2], ova) <= FILM_TOL
+            spectral_xyz = a[2]
+        else:
+            assert cases.xyz_rel_err(a[2], spectral_xyz) <= 1e-11
+
+
+def test_tail_in_trace_kernel_on_tiles_groups_row_blocks_and_a_pool_that_runs_out(monkeypatch):
+    """The same A/B (drt_trace_kernel<true, true> against DRT_TRACE_TAIL=0) along every way a launch can be shaped: a strided
+    sub-rectangle of the image, a device group of three contexts, drt_render() and the one-shot drt_render_tile() in row
+    blocks, and a record pool that runs out and is rendered again. Bit-identical each time."""
+    box = pydrt.load_scene(cases.scene_path("cornell_large_box.scn"), 40, 33)
+    base = dict(spp=5, max_depth=16, seed=9)
+
+    def ab(fn):
+        monkeypatch.delenv("DRT_TRACE_TAIL", raising=False)
+        on = fn()
+        monkeypatch.setenv("DRT_TRACE_TAIL", "0")
+        off = fn()
+        monkeypatch.delenv("DRT_TRACE_TAIL")
+        return on, off
+
+    def same_films(x, y):
+        return all(np.array_equal(a, b) for a, b in zip(x, y))
+
+    # a strided sub-rectangle, samples split over two calls with a first_sample of their own
+    pt = pydrt.make_params(40, 33, x0=3, y0=2, tile_w=31, tile_h=9, row_stride=3, first_sample=2, batch_spp=2, **base)
+    on, off = ab(lambda: _render_all(box, pt))
+    assert on[3].path_flags & pydrt.PATH_TRACE_TAIL and not (off[3].path_flags & pydrt.PATH_TRACE_TAIL)
+    assert same_films(on[0], off[0]) and np.array_equal(on[1], off[1]) and _counts(on[3]) == _counts(off[3])
+    opx, _, ova, ohits, _ = O.oracle_render_tile(box, pt, want_hits=True, math_mode=O.MATH_DEVICE)
+    assert np.array_equal(on[1], ohits) and cases.rel_err(on[0][0], opx) <= FILM_TOL and cases.rel_err(on[0][2], ova) <= FILM_TOL
+
+    # a device group: three contexts on this GPU, rows dealt cyclically
+    pg = pydrt.make_params(40, 33, **base)
+
+    def group():
+        g = pydrt.Group(box, pg, [0, 0, 0])
+        g.render(0, 2)
+        g.render(2, 3)
+        film, st = g.read_film(), g.stats()
+        g.close()
+        return film, st
+    on, off = ab(group)
+    assert on[1].path_flags & pydrt.PATH_TRACE_TAIL and same_films(on[0], off[0]) and _counts(on[1]) == _counts(off[1])
+    whole = _render_all(box, pg, record_hits=False)
+    assert same_films(on[0], whole[0]) and _counts(on[1]) == _counts(whole[3])
+
+    # drt_render() in row blocks (few samples a pair, many samples a call)
+    tall = pydrt.load_scene(cases.scene_path("cornell_large_box.scn"), 64, 160)
+    pb = pydrt.make_params(64, 160, spp=14, max_depth=8, seed=2, batch_spp=2)
+
+    def blocks():
+        r = pydrt.Renderer(tall, pb)
+        r.render(0, 14)
+        film, st = r.read_film(), r.stats()
+        r.close()
+        return film, st
+    on, off = ab(blocks)
+    assert on[1].path_flags & pydrt.PATH_TRACE_TAIL and same_films(on[0], off[0]) and _counts(on[1]) == _counts(off[1])
+    monkeypatch.setenv("DRT_NO_ROW_BLOCKS", "1")
+    plain = blocks()
+    monkeypatch.delenv("DRT_NO_ROW_BLOCKS")
+    assert same_films(on[0], plain[0])
+
+    # the one-shot call in row blocks (2^18 pixels and more), and with a pool that runs out in a block
+    big = pydrt.load_scene(cases.scene_path("cornell_large_box.scn"), 512, 512)
+    po = pydrt.make_params(512, 512, spp=6, max_depth=6, seed=3, batch_spp=4, flags=pydrt.FLAG_FILM_ZERO)
+    on, off = ab(lambda: pydrt.render_tile(big, po))
+    assert on[3].path_flags & pydrt.PATH_TRACE_TAIL and same_films(on[:3], off[:3]) and _counts(on[3]) == _counts(off[3])
+    monkeypatch.setenv("DRT_POOL_BLOCKS", "1")
+    monkeypatch.setenv("DRT_ONESHOT_BLOCKS", "2")
+    redo = pydrt.render_tile(big, po)
+    monkeypatch.delenv("DRT_ONESHOT_BLOCKS")
+    assert redo[3].redone_launches >= 1 and same_films(redo[:3], on[:3]) and _counts(redo[3]) == _counts(on[3])
+    # a session whose pool runs out in the middle of several queued pairs, hit log on
+    ps = pydrt.make_params(40, 33, spp=9, max_depth=16, seed=9, batch_spp=4)
+    small = _render_all(box, ps)
+    monkeypatch.delenv("DRT_POOL_BLOCKS")
+    roomy = _render_all(box, ps)
+    assert small[3].redone_launches >= 1 and roomy[3].redone_launches == 0 and small[3].path_flags & pydrt.PATH_TRACE_TAIL
+    assert same_films(small[0], roomy[0]) and np.array_equal(small[1], roomy[1]) and _counts(small[3]) == _counts(roomy[3])
+
+
+def test_config1_at_its_stated_size_whole_frame():
+    """BASELINE configs[0] exactly as named -- init_cornell.scn 256x256, 4 spp, depth 4, fixed seed -- on the HIP path: every
+    hit index, the statistics and the whole film against the oracle (262 144 paths)."""
+    bundle = pydrt.load_scene(cases.scene_path("init_cornell.scn"), 256, 256)
+    p = pydrt.make_params(256, 256, spp=4, max_depth=4, seed=1)
+    film, hits, xyz, st = _render_all(bundle, p)
+    opx, oav, ova, ohits, ost = O.oracle_render_tile(bundle, p, want_hits=True, math_mode=O.MATH_DEVICE, num_threads=8)
+    assert st.paths == 256 * 256 * 4 and np.array_equal(hits, ohits) and _counts(st) == _counts(ost)
+    assert cases.rel_err(film[0], opx) <= FILM_TOL and cases.rel_err(film[1], oav) <= FILM_TOL and cases.rel_err(film[2], ova) <= FILM_TOL
+    assert cases.xyz_rel_err(xyz, O.oracle_film_to_xyz(bundle, opx)) <= XYZ_TOL
+    assert st.path_flags & pydrt.PATH_TRACE_TAIL  # the legacy scene is all plastic: this is the trace_tail path
+    assert st.launches >= 1 and 0.0 < st.min_sample_ms <= st.avg_sample_ms <= st.max_sample_ms
+
+
+@pytest.mark.parametrize("name", list(cases.NAN_CASES))
+def test_nan_camera_scene_gives_the_reference_film_nan_for_nan(name, golden_dir):
+    """example_scene.scn (a shipped scene whose camera has no fov / fdepth / flength, cases.NAN_CASES): every ray is NaN, nothing
+    is hit, the film is NaN where the reference's is and the filter sums count the samples."""
+    bundle, params = cases.load_case(name)
+    px, av, va, hits, xyz, st = hip_render(bundle, params)
+    opx, oav, ova, ohits, ost = O.oracle_render_tile(bundle, params, want_hits=True, math_mode=O.MATH_DEVICE)
+    assert np.array_equal(hits, ohits) and (hits[:, 0] == -1).all() and _counts(st) == _counts(ost)
+    assert fuzz_scenes.same(px, opx) and fuzz_scenes.same(av, oav) and fuzz_scenes.same(va, ova)
+    g = np.load(os.path.join(golden_dir, "render_%s.npz" % name), allow_pickle=False)
+    assert fuzz_scenes.same(px, g["pixels"]) and fuzz_scenes.same(av, g["avgs"]) and fuzz_scenes.same(va, g["vars"])
+    assert np.isnan(px[:, :bundle.S]).all() and np.all(px[:, bundle.S] == float(params.spp))
+
+
+def test_bvh_box_test_never_rejects_a_box_the_ray_enters():
+    """The hierarchy's f32 slab test (bvh_box_entry, called through drt_selftest_unit) against the exact test in f64 on the box
+    shrunk by the builder's padding (2^-19 E): whatever the exact test accepts the f32 test must accept, with an entry bound
+    that is not beyond the exact entry -- in particular for rays PARALLEL to an axis (a direction component of exactly 0, or
+    one that flushes to 0 / overflows 1/d in f32) whose origin lies inside that slab, the case ADVICE r2 found rejected."""
+    rng = np.random.default_rng(12)
+    n = 20000
+    E = 64.0
+    pad = E * 2.0 ** -19
+    lo = rng.uniform(-E, E, (n, 3)); hi = lo + rng.uniform(0.01, 30.0, (n, 3))
+    lo32, hi32 = lo.astype(np.float32).astype(np.float64), hi.astype(np.float32).astype(np.float64)
+    o = rng.uniform(-E, E, (n, 3))
+    inside = rng.random(n) < 0.5
+    o[inside] = (lo32 + (hi32 - lo32) * rng.uniform(0.05, 0.95, (n, 3)))[inside]
+    d = rng.normal(size=(n, 3))
+    kinds = rng.integers(0, 6, n)
+    axis = rng.integers(0, 3, n)
+    tiny = np.array([0.0, -0.0, 1e-40, -1e-39, 3e-39, 1e-31])[kinds]
+    par = rng.random(n) < 0.6
+    d[np.arange(n)[par], axis[par]] = tiny[par]
+    two = par & (rng.random(n) < 0.3)  # parallel to two axes at once
+    d[np.arange(n)[two], (axis[two] + 1) % 3] = 0.0
+    d /= np.sqrt((d * d).sum(axis=1))[:, None]
+    got = pydrt.selftest_unit(pydrt.UNIT_BVH_BOX, np.hstack([o, d, lo32, hi32]))[:, 0]
+    # the exact test on the box less the padding, in f64 with the division made safe
+    ilo, ihi = lo32 + pad, hi32 - pad
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        t0, t1 = (ilo - o) / d, (ihi - o) / d
+    tn, tf = np.minimum(t0, t1), np.maximum(t0, t1)
+    parallel = np.abs(d) < 1e-300
+    within = (o >= ilo) & (o <= ihi)
+    tn = np.where(parallel, np.where(within, -np.inf, np.inf), tn)
+    tf = np.where(parallel, np.where(within, np.inf, -np.inf), tf)
+    enter, leave = tn.max(axis=1), tf.min(axis=1)
+    accept = (enter <= leave) & (leave >= 0.0)
+    assert accept.sum() > n // 4 and (accept & par).sum() > 1000
+    assert np.all(got[accept] >= 0.0), "%d boxes the ray enters were rejected" % int((got[accept] < 0).sum())
+    assert np.all(got[accept] <= np.maximum(enter[accept], 0.0) * (1 + 1e-6) + 1e-3)
+    # a ray parallel to an axis with its origin well outside that slab misses the box, and the f32 test may say so
+    away = par & ~two & ((o[np.arange(n), axis] < lo32[np.arange(n), axis] - 1.0) | (o[np.arange(n), axis] > hi32[np.arange(n), axis] + 1.0)) & (np.abs(tiny) < 1e-38)
+    assert away.sum() > 100 and np.all(got[away] < 0.0)
+    # the advisor's example
+    one = pydrt.selftest_unit(pydrt.UNIT_BVH_BOX, np.array([[0.3, 0.0, 5.0, 0.0, 0.1 / np.hypot(0.1, 1.0), -1.0 / np.hypot(0.1, 1.0), -1, -1, -1, 1, 1, 1]], dtype=np.float64))
+    assert one[0, 0] >= 0.0
+
+
+def test_axis_parallel_camera_rays_through_the_hierarchy(monkeypatch):
+    """End to end for the same finding: an off-axis pinhole camera and pixel centres (FILM_SAMPLE_CENTER) give camera rays with a
+    direction component of exactly 0 and an origin that is not 0 on that axis; forced through the hierarchy (DRT_FORCE_BVH) the
+    boxes that straddle the origin's coordinate must still be entered: hit indices equal the oracle's linear scan."""
+    import re
+    text = open(cases.scene_path("cornell_plane_light.scn")).read()
+    text = re.sub(r"position\s+0\.0,\s*0\.0,\s*8\.0", "position 0.25, 0.5, 8.0", text, count=1)
+    text = re.sub(r"target\s+0\.0,\s*0\.0,\s*0\.0", "target 0.25, 0.5, 0.0", text, count=1)
+    b = pydrt.load_scene_text(text, 9, 9)
+    cam = b.camera
+    zero = 0
+    for y in range(9):
+        for x in range(9):
+            pp = np.array(cam.right) * ((x + 0.5) * cam.pixel_width) + np.array(cam.up) * ((y + 0.5) * cam.pixel_height) + np.array(cam.film_bottom_left)
+            dd = np.array(cam.aperture_position) - pp
+            zero += int(dd[0] == 0.0 or dd[1] == 0.0)
+    assert zero >= 9  # the centre column and the centre row
+    p = pydrt.make_params(9, 9, spp=2, max_depth=8, seed=4, pixel_scheme=pydrt.FILM_SAMPLE_CENTER)
+    opx, oav, ova, ohits, ost = O.oracle_render_tile(b, p, want_hits=True, math_mode=O.MATH_DEVICE)
+    monkeypatch.setenv("DRT_FORCE_BVH", "1")
+    px, av, va, hits, xyz, st = hip_render(b, p)
+    monkeypatch.delenv("DRT_FORCE_BVH")
+    assert st.path_flags & pydrt.PATH_BVH
+    assert np.array_equal(hits, ohits), "%d closest-hit indices differ" % int((hits != ohits).sum())
+    assert (ohits.reshape(2, 9, 9, -1)[0, :, 4, 0] >= 0).all()  # the centre column's camera rays do hit something
+    assert _counts(st) == _counts(ost) and cases.rel_err(px, opx) <= FILM_TOL and cases.rel_err(va, ova) <= FILM_TOL
+
+
+def test_xyz_and_bmp_bytes_of_a_film_whose_pool_ran_out(monkeypatch):
+    """drt_read_xyz / drt_read_bgra straight after drt_render, with a record pool that ran out on the way: the
+    conversion must see the film AFTER the skipped samples were rendered again, not the incomplete one."""
+    bundle, _ = cases.load_case("plane_light_48")
+    p = pydrt.make_params(48, 48, spp=30, max_depth=8, seed=3, batch_spp=12)
+    r = pydrt.Renderer(bundle, p)
+    r.render(0, 30)
+    want_xyz, want_bgra = r.read_xyz(), [r.read_bgra(k) for k in range(3)]
+    r.close()
+    monkeypatch.setenv("DRT_POOL_BLOCKS", "1")
+    for first in ("xyz", "bgra"):
+        r = pydrt.Renderer(bundle, p)
+        r.render(0, 30)
+        if first == "xyz":
+            got_xyz = r.read_xyz()       # nothing has synchronised yet: the redo happens inside this call
+            got_bgra = [r.read_bgra(k) for k in range(3)]
+        else:
+            got_bgra = [r.read_bgra(k) for k in range(3)]
+            got_xyz = r.read_xyz()
+        assert r.stats().redone_launches >= 1
+        r.close()
+        assert np.array_equal(got_xyz, want_xyz) and all(np.array_equal(a, b) for a, b in zip(got_bgra, want_bgra)), first
+    g = pydrt.Group(bundle, p, [0, 0])
+    g.render(0, 30)
+    st = g.stats()
+    g.close()
+    assert st.redone_launches >= 1 and st.record_pool_blocks > 0 and st.record_block_bytes > 0  # a group reports what its contexts did
+
+
+def test_reference_side_binding_drives_the_hip_library():
+    """INTEGRATION.md's reference-side stub (include/drt_reference_binding.inc, compiled against the reference's own headers in
+    oracle/_ref) with libdrt_hip.so's drt_render_tile behind it: the reference's scene_data / camera_data / config go in, the
+    film that comes back is the film of the reference's own pixel loop (src/daily_ray_trace.c:709-752) on that scene."""
+    if not O.ref_available():
+        pytest.skip("oracle/_ref was not built (it is built where /root/reference exists and travels as a library)")
+    R = O.ref_lib()
+    L = pydrt.hip_lib()
+    for name in ("plane_light_16", "gold_mirror", "lights", "init_cornell"):
+        bundle, params = cases.load_case(name)
+        R.ref_set_scene(C.byref(bundle.scene))
+        S, n = bundle.S, int(params.width) * int(params.height)
+        px, av, va = np.zeros((n, S + 1)), np.zeros((n, S)), np.zeros((n, S))
+        p1 = pydrt.make_params(int(params.width), int(params.height), spp=int(params.spp), max_depth=int(params.max_depth), seed=1,
+                               pixel_scheme=int(params.pixel_scheme))
+        fn = C.cast(L.drt_render_tile, O.RENDER_TILE_FN)
+        rc = R.ref_run_binding(C.byref(bundle.camera), C.byref(p1), fn, O._ptr(px), O._ptr(av), O._ptr(va))
+        assert rc == 0, L.drt_last_error()
+        rp, ra, rv = O.ref_render_tile(bundle, p1)
+        assert np.array_equal(px[:, S], rp[:, S])
+        assert cases.rel_err(px, rp) <= FILM_TOL and cases.rel_err(av, ra) <= FILM_TOL and cases.rel_err(va, rv) <= FILM_TOL, name
+
+
+def test_rccl_one_rank_gather_of_a_film_block():
+    """RCCL itself, on the one GPU there is: a 1-rank process group with backend "nccl" (= RCCL), a real film block rendered on
+    the device into a drt_dist.FilmGather buffer, gathered by the collective bench.py uses at N > 1 (always_collective: a world
+    of one otherwise just copies) and de-interleaved into the frame -- the frame equals the film read back directly. Run in a
+    child process, so the process group does not outlive the test."""
+    import subprocess
+    import sys
+    import textwrap
+    pytest.importorskip("torch")
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path[:0] = [%r, %r]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch, torch.distributed as dist
+        import pydrt, drt_dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        W, H = 96, 40
+        bundle = pydrt.load_scene(%r, W, H)
+        S = bundle.S
+        dev = torch.device("cuda", 0)
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        blocks = []
+        image = None
+        per = 16
+        for j0 in range(0, H, per):
+            fb = drt_dist.FilmGather(H, W, S, 0, 1, dev, j0=j0, block_rows=min(per, H - j0), image=image, always_collective=True)
+            image = fb.image
+            blocks.append(fb)
+        films = []
+        for fb in blocks:
+            y0, rows, stride = fb.tile()
+            p = pydrt.make_params(W, H, spp=3, max_depth=6, seed=2, y0=y0, tile_h=rows, row_stride=stride)
+            r = pydrt.Renderer(bundle, p)
+            r.bind_film(fb.region(0).data_ptr(), fb.region(1).data_ptr(), fb.region(2).data_ptr())
+            r.set_stream(stream.cuda_stream)
+            r.render(0, 3)
+            fb.gather_async()
+            films.append(r)
+        for fb in blocks:
+            fb.finish()
+        torch.cuda.synchronize()
+        whole = pydrt.Renderer(bundle, pydrt.make_params(W, H, spp=3, max_depth=6, seed=2))
+        whole.render(0, 3)
+        px, av, va = whole.read_film()
+        ok = all(torch.equal(image[i].cpu().reshape(W * H, -1), torch.from_numpy(a)) for i, a in enumerate((px, av, va)))
+        t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        print("RCCL_OK" if ok and float(t.item()) == 1.5 and float(px.sum()) > 0 else "RCCL_MISMATCH", dist.get_backend())
+        for r in films: r.close()
+        whole.close()
+        dist.destroy_process_group()
+    """) % (os.path.join(cases.REPO, "daily-ray-trace_amd"), os.path.join(cases.REPO, "tests"), cases.scene_path("cornell_plane_light.scn"))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "RCCL_OK nccl" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

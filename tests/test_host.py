@@ -31,7 +31,7 @@ def test_hip_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     assert C.sizeof(pydrt.Surface) == 4 + 4 + 24 + 8 + 72
     assert C.sizeof(pydrt.Camera) == 20 * 8
-    assert C.sizeof(pydrt.Stats) == 8 * 8 + 8 + 8 + 4 + 4  # + record pool: blocks, peak, block bytes, redone launches
+    assert C.sizeof(pydrt.Stats) == 8 * 8 + 8 + 8 + 4 + 4 + 4 + 4 + 3 * 8  # + record pool: blocks, peak, block bytes, redone launches; + kernel pairs, pad, min / max / avg sample pass
     assert C.sizeof(pydrt.Params) == 72
 
 
@@ -206,12 +206,12 @@ def test_spd_to_bmp_postprocess(tmp_path, golden_dir):
     assert np.all(px[:, 3] == 255)
 
 
-def _config_for(workdir):
+def _config_for(workdir, scene="scenes/cornell_plane_light.scn", depth=4, scheme="pixel_random"):
     """A config_arguments (1136 bytes, the reference's layout) whose outputs live under workdir."""
     H = pydrt.host_lib()
-    text = ("num_pixel_samples 6\nmax_cast_depth 4\noutput_width 5\noutput_height 3\nmin_wl 380.0\nmax_wl 720.0\nwl_interval 5.0\n"
-            "pixel_scheme pixel_random\ninput_scene scenes/cornell_plane_light.scn\n"
-            "output_spd %s/output.spd\naverage_spd %s/average.spd\nvariance_spd %s/variance.spd\n" % (workdir, workdir, workdir)).encode()
+    text = ("num_pixel_samples 6\nmax_cast_depth %d\noutput_width 5\noutput_height 3\nmin_wl 380.0\nmax_wl 720.0\nwl_interval 5.0\n"
+            "pixel_scheme %s\ninput_scene %s\n"
+            "output_spd %s/output.spd\naverage_spd %s/average.spd\nvariance_spd %s/variance.spd\n" % (depth, scheme, scene, workdir, workdir, workdir)).encode()
     buf = C.create_string_buffer(1136)
     tb = C.create_string_buffer(text, len(text) + 1)
     H.parse_config.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p]
@@ -221,8 +221,9 @@ def _config_for(workdir):
 
 
 def test_checkpoint_sets_are_crash_safe_and_resume_refuses_mixed_files(tmp_path):
-    """a checkpoint is four files; a kill between them must never let a later resume continue from a mixed
-    set. Files go through .tmp + rename with a manifest written last, and the loader refuses anything inconsistent."""
+    """A checkpoint is three generation files + a manifest that names the generation; the manifest's rename is the one
+    switch, so a kill at any moment leaves the previous complete checkpoint or the new one, and the loader
+    refuses anything inconsistent with the files or with the job (size, grid, seed, depth, pixel scheme, scene file)."""
     import shutil
     H = pydrt.host_lib()
     f64p = C.POINTER(C.c_double)
@@ -236,6 +237,8 @@ def test_checkpoint_sets_are_crash_safe_and_resume_refuses_mixed_files(tmp_path)
     rng = np.random.default_rng(3)
     import tempfile
     short = tempfile.mkdtemp(prefix="ck", dir="/tmp")  # config_arguments path fields hold 63 characters (src/daily_ray_trace.h:36-52)
+    scene = os.path.join(short, "s.scn")
+    open(scene, "w").write("Camera\n")
 
     def film(n):
         """a film that is consistent with n samples: sums, filter = n, mean = sum / n, variance >= 0"""
@@ -244,7 +247,7 @@ def test_checkpoint_sets_are_crash_safe_and_resume_refuses_mixed_files(tmp_path)
 
     def write(d, n, seed=1, raw=1):
         os.makedirs(d, exist_ok=True)
-        cfg = _config_for(d)
+        cfg = _config_for(d, scene)
         px, av, va = film(n)
         assert H.drt_host_write_outputs(cfg, w, h, S, 380.0, 5.0, px.ctypes.data_as(f64p), av.ctypes.data_as(f64p), va.ctypes.data_as(f64p), raw, n, seed) == 0
         return cfg, px, av, va
@@ -255,37 +258,71 @@ def test_checkpoint_sets_are_crash_safe_and_resume_refuses_mixed_files(tmp_path)
         rc = H.drt_host_load_checkpoint(cfg, size[0], size[1], S, seed, a.ctypes.data_as(f64p), b.ctypes.data_as(f64p), c.ctypes.data_as(f64p), C.byref(done))
         return rc, done.value, a, b, c, H.drt_host_checkpoint_error().decode()
 
+    def generation(d):
+        return int([l for l in open(os.path.join(d, "output.spd.ckpt")).read().splitlines() if l.startswith("generation")][0].split()[1])
+
     d2 = os.path.join(short, "n4")
     cfg, px, av, va = write(d2, 4)
     assert not [f for f in os.listdir(d2) if f.endswith(".tmp")]          # nothing half-written is left behind
-    assert sorted(os.listdir(d2)) == ["average.spd", "output.spd", "output.spd.ckpt", "variance.spd", "variance.spd.raw"]
+    assert sorted(os.listdir(d2)) == ["average.spd", "average.spd.ck0", "output.spd", "output.spd.ck0", "output.spd.ckpt", "variance.spd", "variance.spd.raw.ck0"]
     rc, done, a, b, c, why = load(cfg)
     assert rc == 0 and done == 4 and np.array_equal(a, px) and np.array_equal(b, av) and np.array_equal(c, va)
-    # the advisor's case: output.spd already at N2 = 4 samples, average.spd still from N1 = 2
+    # the reference's outputs under their own names hold the same film (and the normalised variance)
+    assert open(os.path.join(d2, "output.spd"), "rb").read() == open(os.path.join(d2, "output.spd.ck0"), "rb").read()
+    nv = np.fromfile(os.path.join(d2, "variance.spd"), dtype=np.float64, offset=40).reshape(n_px, S)
+    assert np.array_equal(nv, va / va.max(axis=1, keepdims=True))
+    # the next checkpoint goes to the other generation and retires this one
+    cfg, px6, av6, va6 = write(d2, 6)
+    assert generation(d2) == 1 and not os.path.exists(os.path.join(d2, "output.spd.ck0"))
+    rc, done, a, *_ = load(cfg)
+    assert rc == 0 and done == 6 and np.array_equal(a, px6)
+    # a kill while the NEXT checkpoint's files are being written (generation 0 half there, manifest not switched yet):
+    # the previous checkpoint still stands, whole
+    open(os.path.join(d2, "output.spd.ck0"), "wb").write(b"half a file")
+    open(os.path.join(d2, "average.spd.ck0"), "wb").write(b"")
+    rc, done, a, b, c, why = load(cfg)
+    assert rc == 0 and done == 6 and np.array_equal(a, px6) and np.array_equal(b, av6) and np.array_equal(c, va6)
+    # ... and a kill right after the switch leaves the new one whole: the older generation's files may still lie around
+    cfg, px8, *_ = write(d2, 8)
+    assert generation(d2) == 0
+    open(os.path.join(d2, "output.spd.ck1"), "wb").write(b"left over")
+    rc, done, a, *_ = load(cfg)
+    assert rc == 0 and done == 8 and np.array_equal(a, px8)
+    os.remove(os.path.join(d2, "output.spd.ck1"))
+    # files of two checkpoints mixed under one manifest: mean of N1 = 2 samples beside sums of N2 = 8
     d1 = os.path.join(short, "n2")
     write(d1, 2)
-    shutil.copy(os.path.join(d1, "average.spd"), os.path.join(d2, "average.spd"))
+    shutil.copy(os.path.join(d1, "average.spd.ck0"), os.path.join(d2, "average.spd.ck0"))
     rc, done, *_, why = load(cfg)
     assert rc != 0 and done == 0 and "does not belong" in why
     # the whole older set under a newer manifest: the filter sums give it away
+    shutil.rmtree(d2)
     cfg, *_ = write(d2, 4)
-    shutil.copy(os.path.join(d1, "output.spd"), os.path.join(d2, "output.spd"))
+    shutil.copy(os.path.join(d1, "output.spd.ck0"), os.path.join(d2, "output.spd.ck0"))
     rc, done, *_, why = load(cfg)
     assert rc != 0 and "manifest says 4" in why
-    # a kill between the renames and the manifest: no manifest, no resume
+    # no manifest, no resume
+    shutil.rmtree(d2)
     cfg, *_ = write(d2, 4)
     os.remove(os.path.join(d2, "output.spd.ckpt"))
     rc, done, *_, why = load(cfg)
     assert rc != 0 and "manifest" in why
-    # a final write without the raw variance retires the manifest of the set it overwrote
+    # a final write without the raw variance retires the checkpoint it overwrote
+    shutil.rmtree(d2)
     cfg, *_ = write(d2, 4)
     write(d2, 6, raw=0)
-    assert not os.path.exists(os.path.join(d2, "output.spd.ckpt")) and load(cfg)[0] != 0
-    # other job: another seed, another size; a truncated file; a file of another size with a forged header
+    assert sorted(os.listdir(d2)) == ["average.spd", "output.spd", "variance.spd"] and load(cfg)[0] != 0
+    # other job: another seed, size, depth, pixel scheme, scene file; a truncated file; a file of another size with a forged header
     cfg, *_ = write(d2, 4)
     assert load(cfg, seed=2)[0] != 0 and "seed" in load(cfg, seed=2)[5]
     assert load(cfg, size=(3, 5))[0] != 0
-    raw_path = os.path.join(d2, "variance.spd.raw")
+    assert "max_cast_depth" in load(_config_for(d2, scene, depth=5))[5]
+    assert "pixel scheme" in load(_config_for(d2, scene, scheme="pixel_center"))[5]
+    open(scene, "a").write("# edited\n")
+    assert "another scene" in load(cfg)[5]
+    cfg, *_ = write(d2, 4)
+    assert load(cfg)[0] == 0
+    raw_path = os.path.join(d2, "variance.spd.raw.ck%d" % generation(d2))
     data = open(raw_path, "rb").read()
     open(raw_path, "wb").write(data[:-8])
     rc, _, _, _, _, why = load(cfg)

@@ -198,6 +198,19 @@ def test_render_matches_reference_film(L, golden_dir, name):
     O.set_math_mode(O.MATH_REFERENCE)
 
 
+@pytest.mark.parametrize("name", list(cases.NAN_CASES))
+def test_render_matches_reference_film_nan_for_nan(L, golden_dir, name):
+    """example_scene.scn (cases.NAN_CASES): the reference's film for a camera that is all NaN, kept whole in the fixture."""
+    import fuzz_scenes
+    g = load(golden_dir, "render_%s.npz" % name)
+    bundle, params = cases.load_case(name)
+    for mode in (O.MATH_REFERENCE, O.MATH_DEVICE):
+        px, av, va, hits, st = O.oracle_render_tile(bundle, params, want_hits=True, math_mode=mode)
+        assert fuzz_scenes.same(px, g["pixels"]) and fuzz_scenes.same(av, g["avgs"]) and fuzz_scenes.same(va, g["vars"])
+        assert (hits[:, 0] == -1).all() and st.closest_hit_scans == st.paths
+    O.set_math_mode(O.MATH_REFERENCE)
+
+
 def test_threads_and_tiles_reproduce_single_thread(L):
     """Per-path seeding makes the result independent of traversal order: rows split over threads, and a
     row-cyclic pair of tiles, give the bits of the single-thread full-frame render."""

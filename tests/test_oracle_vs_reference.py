@@ -19,6 +19,17 @@ def test_film_bit_identical(name):
     assert np.array_equal(rp, op) and np.array_equal(ra, oa) and np.array_equal(rv, ov, equal_nan=True)
 
 
+@pytest.mark.parametrize("name", list(cases.NAN_CASES))
+def test_film_bit_identical_nan_for_nan(name):
+    """example_scene.scn: a camera without fov / fdepth / flength makes every ray NaN (cases.NAN_CASES); the reference's film is
+    NaN in every wavelength and the filter sums still count the samples -- and so is the oracle's, NaN for NaN."""
+    bundle, params = cases.load_case(name)
+    rp, ra, rv = O.ref_render_tile(bundle, params)
+    op, oa, ov, _, st = O.oracle_render_tile(bundle, params, math_mode=O.MATH_REFERENCE)
+    assert fuzz_scenes.same(op, rp) and fuzz_scenes.same(oa, ra) and fuzz_scenes.same(ov, rv)
+    assert np.isnan(rp[:, :bundle.S]).all() and np.all(rp[:, bundle.S] == float(params.spp)) and st.shaded_vertices == 0
+
+
 def test_config1_full_size_bit_identical():
     """BASELINE.json configs[0]: init_cornell.scn 256x256, 4 spp, depth 4, single thread, fixed seed."""
     bundle = pydrt.load_scene(cases.scene_path("init_cornell.scn"), 256, 256)

@@ -27,7 +27,7 @@ import json
 import os
 import sys
 
-KERNELS = {"shade": "drt_shade_kernel", "trace": "drt_trace_kernel"}
+KERNELS = {"shade": "drt_shade_kernel", "trace": "drt_trace_kernel", "primary": "drt_primary_kernel", "bounce": "drt_bounce_kernel"}
 N_SIMD = 1024          # 256 CUs x 4 SIMDs
 N_SE = 32              # SQ_BUSY_CYCLES is summed over the shader engines
 N_XCD = 8              # GRBM_GUI_ACTIVE is summed over the XCDs
@@ -88,7 +88,9 @@ def main():
     a = ap.parse_args()
     trace = read_trace(a.root)
     agg, disp, span, regs = read_counters(a.root)
-    out = {"workload": a.workload, "paths_per_launch": a.paths_per_launch, "source": a.source or os.path.relpath(a.root),
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench import csrc_sha  # the kernel sources these counters were taken from: bench.py drops `frac` when its build is another one
+    out = {"workload": a.workload, "paths_per_launch": a.paths_per_launch, "source": a.source or os.path.relpath(a.root), "csrc_sha": csrc_sha(),
            "units": "per path unless a key says otherwise; cycles are shader-clock cycles", "kernels": {}}
     for k in KERNELS:
         if k not in agg:
