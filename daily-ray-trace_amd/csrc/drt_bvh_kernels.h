@@ -255,50 +255,128 @@ __device__ __forceinline__ int stack_pop(const int *stack, uint32_t lane, int &s
     return BVH_DONE;
 }
 
-__device__ __forceinline__ void bvh_walk(const SceneView &sv, int *stack, uint32_t lane, int job, V3 o, V3 d, double &limit, int &index,
+#ifndef DRT_BVH_POSTPONE
+#define DRT_BVH_POSTPONE 4 /* leaves a lane may put aside before it has to wait for the wave's leaf phase (0: the plain while-while walk) */
+#endif
+#ifndef DRT_BVH_POSTPONE_EXIT
+#define DRT_BVH_POSTPONE_EXIT 16 /* the node phase ends when fewer lanes than this are still walking and one of the others waits with a full queue */
+#endif
+#define BVH_QUEUE_WORDS ((DRT_BVH_POSTPONE > 0 ? DRT_BVH_POSTPONE : 1) * 64)
+
+__device__ __forceinline__ void bvh_node_step(const SceneView &sv, int *stack, uint32_t lane, const Ray32 &r32, float lim, int &cur, int &sp)
+{
+    const BvhNode &n = sv.bvh_nodes[cur];
+    int ref[2];
+    float t[2];
+    bool hit[2];
+    bvh_children(n, r32, lim, ref, t, hit);
+    if (hit[0] && hit[1])
+    {
+        const int near = t[1] < t[0] ? 1 : 0;
+        stack[sp * 64 + lane] = ref[1 - near];
+        sp += 1;
+        cur = ref[near];
+    }
+    else if (hit[0]) cur = ref[0];
+    else if (hit[1]) cur = ref[1];
+    else cur = stack_pop(stack, lane, sp);
+}
+
+__device__ __forceinline__ void bvh_walk(const SceneView &sv, int *stack, int *leaf_queue, uint32_t lane, int job, V3 o, V3 d, double &limit, int &index,
                                          bool &occluded)
 {
     const Ray32 r32 = bvh_ray32(o, d);
     float lim = bvh_limit32(limit);
     int sp = 0;
     int cur = job == JOB_NONE ? BVH_DONE : 0;
+#if DRT_BVH_POSTPONE > 0
+    /* "While-while" with leaves PUT ASIDE. In the plain form every lane walks inner nodes until it holds a leaf, and the distance to
+     * the next leaf is so uneven from lane to lane (a handful of nodes on average, fifteen for the unluckiest of 64) that three
+     * lanes in four wait. Here a lane that reaches a leaf notes it in a small queue of its own (LDS, DRT_BVH_POSTPONE entries) and
+     * walks on; the node phase ends when nobody walks any more, or when few lanes do and one of the others waits with a full queue;
+     * then the queued leaves are tested together -- the f32 bound of every one first, the f64 intersector for those it leaves in
+     * the running -- and the walk resumes with the limit they gave. A leaf tested later than the plain form would have tested it
+     * only delays pruning: the result is the same minimum with the same tie-break (closest hit), the same answer to "anything
+     * nearer than the limit?" (shadow ray). */
+    int nq = 0;
     for (;;)
     {
-        while (cur >= 0) /* inner nodes, until the lane holds a leaf */
+        for (;;)
         {
-            const BvhNode &n = sv.bvh_nodes[cur];
-            int ref[2];
-            float t[2];
-            bool hit[2];
-            bvh_children(n, r32, lim, ref, t, hit);
-            if (hit[0] && hit[1])
+            if (bvh_is_leaf(cur) && nq < DRT_BVH_POSTPONE)
             {
-                const int near = t[1] < t[0] ? 1 : 0;
-                stack[sp * 64 + lane] = ref[1 - near];
-                sp += 1;
-                cur = ref[near];
+                leaf_queue[nq * 64 + lane] = cur;
+                nq += 1;
+                cur = stack_pop(stack, lane, sp);
             }
-            else if (hit[0]) cur = ref[0];
-            else if (hit[1]) cur = ref[1];
-            else cur = stack_pop(stack, lane, sp);
+            const bool walking = cur >= 0;
+            const int n_walk = __popcll(__ballot(walking));
+            if (n_walk == 0) break;
+            if (n_walk < DRT_BVH_POSTPONE_EXIT && __any(bvh_is_leaf(cur) && nq == DRT_BVH_POSTPONE)) break;
+            if (walking) bvh_node_step(sv, stack, lane, r32, lim, cur, sp);
         }
-        if (!__any(cur != BVH_DONE)) break;
-        while (bvh_is_leaf(cur)) /* leaves, the wave together */
-        {
-            const int packed = -2 - cur;
-            const int first = packed >> 3, count = (packed & 7) + 1;
-            bool stop = false;
-            for (int k = 0; k < count; k += 1)
+        if (!__any(nq > 0 || cur != BVH_DONE)) break;
+        /* leaf phase, first half: the f32 bound of every queued leaf; those it does not rule out move to the front of the queue */
+        int ns = 0;
+        for (int k = 0; __any(k < nq); k += 1)
+            if (k < nq)
             {
-                /* the whole 64-byte record at once: the centre test below wants its last quarter, the intersector (most lanes' next
-                 * step) its first three, and fetched as they are needed that would be three round trips to L2 */
-                const BvhLeafPrim *src = &sv.bvh_leaf[first + k];
+                const int leaf = leaf_queue[k * 64 + lane];
+                const BvhLeafPrim *src = &sv.bvh_leaf[(-2 - leaf) >> 3];
+                BvhLeafPrim b;
+                b.c32[0] = src->c32[0]; b.c32[1] = src->c32[1]; b.c32[2] = src->c32[2]; b.reach32 = src->reach32;
+                if (!sphere_certainly_missed(b, r32, lim))
+                {
+                    leaf_queue[ns * 64 + lane] = leaf;
+                    ns += 1;
+                }
+            }
+        nq = 0;
+        /* second half: the f64 intersector (src/geometry.c:123-182) */
+        for (int k = 0; __any(k < ns); k += 1)
+            if (k < ns)
+            {
+                const BvhLeafPrim *src = &sv.bvh_leaf[(-2 - leaf_queue[k * 64 + lane]) >> 3];
                 BvhLeafPrim lp;
                 lp.index = src->index; lp.type = src->type;
                 lp.f[0] = src->f[0]; lp.f[1] = src->f[1]; lp.f[2] = src->f[2]; lp.f[3] = src->f[3];
-                lp.c32[0] = src->c32[0]; lp.c32[1] = src->c32[1]; lp.c32[2] = src->c32[2]; lp.reach32 = src->reach32;
-                __asm__ volatile("" : "+v"(lp.index), "+v"(lp.type), "+v"(lp.f[0]), "+v"(lp.f[1]), "+v"(lp.f[2]), "+v"(lp.f[3]));
-                if (sphere_certainly_missed(lp, r32, lim)) continue;
+                const double dist = leaf_distance(sv, lp, o, d);
+                if (job == JOB_CLOSEST)
+                {
+                    if (dist < limit || (dist == limit && (int)lp.index < index))
+                    {
+                        limit = dist;
+                        index = (int)lp.index;
+                        lim = bvh_limit32(limit);
+                    }
+                }
+                else if (dist < limit) /* the reference breaks at the first occluder; which one does not matter */
+                {
+                    occluded = true;
+                    ns = 0;
+                    sp = 0;
+                    cur = BVH_DONE;
+                }
+            }
+    }
+#else
+    for (;;)
+    {
+        while (cur >= 0) bvh_node_step(sv, stack, lane, r32, lim, cur, sp); /* inner nodes, until the lane holds a leaf */
+        if (!__any(cur != BVH_DONE)) break;
+        while (bvh_is_leaf(cur)) /* leaves, the wave together */
+        {
+            /* the whole 64-byte record at once: the centre test below wants its last quarter, the intersector (most lanes' next
+             * step) its first three, and fetched as they are needed that would be three round trips to L2 */
+            const BvhLeafPrim *src = &sv.bvh_leaf[(-2 - cur) >> 3];
+            BvhLeafPrim lp;
+            lp.index = src->index; lp.type = src->type;
+            lp.f[0] = src->f[0]; lp.f[1] = src->f[1]; lp.f[2] = src->f[2]; lp.f[3] = src->f[3];
+            lp.c32[0] = src->c32[0]; lp.c32[1] = src->c32[1]; lp.c32[2] = src->c32[2]; lp.reach32 = src->reach32;
+            __asm__ volatile("" : "+v"(lp.index), "+v"(lp.type), "+v"(lp.f[0]), "+v"(lp.f[1]), "+v"(lp.f[2]), "+v"(lp.f[3]));
+            bool stop = false;
+            if (!sphere_certainly_missed(lp, r32, lim))
+            {
                 double dist = leaf_distance(sv, lp, o, d);
                 if (job == JOB_CLOSEST)
                 {
@@ -310,7 +388,6 @@ __device__ __forceinline__ void bvh_walk(const SceneView &sv, int *stack, uint32
                     }
                 }
                 else if (dist < limit) stop = true; /* the reference breaks at the first occluder; which one does not matter */
-                if (DRT_BVH_ONE_PER_LEAF) break;
             }
             if (stop)
             {
@@ -322,6 +399,7 @@ __device__ __forceinline__ void bvh_walk(const SceneView &sv, int *stack, uint32
         }
         if (!__any(cur != BVH_DONE)) break;
     }
+#endif
 }
 
 __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_bounce_kernel(
@@ -330,6 +408,7 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
     const uint64_t *__restrict__ queue, const unsigned long long *__restrict__ queue_count)
 {
     __shared__ int s_stack[BOUNCE_BLOCK / 64][BVH_LDS_STACK * 64];
+    __shared__ int s_leaf_queue[BOUNCE_BLOCK / 64][BVH_QUEUE_WORDS];
     SceneView sv;
     sv.n_surf = sc.n_surf; sv.n_lights = sc.n_lights;
     sv.surf = sc.surf; sv.lights = sc.lights; sv.surf_type = sc.surf_type; sv.surf_mat = sc.surf_mat;
@@ -337,6 +416,7 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
     sv.bvh_nodes = sc.bvh_nodes; sv.bvh_leaf = sc.bvh_leaf;
     const uint32_t lane = threadIdx.x & 63u;
     int *stack = s_stack[threadIdx.x >> 6];
+    int *leaf_queue = s_leaf_queue[threadIdx.x >> 6];
     if (*tp.overflow) return;
     const uint64_t n_work = *queue_count;
     const uint64_t CHUNK = tp.chunk;
@@ -501,7 +581,7 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
         }
         int index = -1;
         bool occluded = false;
-        bvh_walk(sv, stack, lane, job, jo, jd, limit, index, occluded);
+        bvh_walk(sv, stack, leaf_queue, lane, job, jo, jd, limit, index, occluded);
 
         /* ---- what the job was for ---- */
         if (job == JOB_CLOSEST)
@@ -568,9 +648,7 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
             vrec[0] = mat.bdsf_packed;
             vrec[1] = (uint64_t)mat.num_bdsfs | ((uint64_t)(e.flags | mat.vertex_flags) << 8) | ((uint64_t)((uint32_t)mat.diffuse_spd & 0xFFFFu) << 16) |
                       ((uint64_t)((uint32_t)mat.glossy_spd & 0xFFFFu) << 32) | ((uint64_t)((uint32_t)mat.mirror_spd & 0xFFFFu) << 48);
-            vrec[2] = (uint64_t)((uint32_t)sv.mats[ip.incident_mat].refract_spd & 0xFFFFu) |
-                      ((uint64_t)((uint32_t)sv.mats[ip.transmit_mat].refract_spd & 0xFFFFu) << 16) |
-                      ((uint64_t)((uint32_t)sv.mats[ip.transmit_mat].extinct_spd & 0xFFFFu) << 32);
+            vrec[2] = record_media_word(sc, sv, ip);
             vrec[3] = (uint64_t)__double_as_longlong(ip.on_dot);
             vrec[4] = (uint64_t)__double_as_longlong(dir_pdf);
             store_coef(vrec + 5, e);

@@ -303,6 +303,61 @@ __device__ __forceinline__ double conductor_reflectance(double ir, double tr, do
     return 0.5 * (par + per);
 }
 
+/* The same two terms with what depends on the PAIR of media only taken out of the loop over vertices: for a vertex whose
+ * incident / transmit materials are the scene's base material and the surface's own (every vertex but those met from inside a
+ * second object), the launcher tabulates per wavelength
+ *     rel_sq = (ir / tr) * (ir / tr)                              fs_dielectric_reflectance, src/bdsf.c:52-56
+ *     cA = (tr/ir)^2 - (te/ir)^2,  cB = (4 (tr/ir)^2) (te/ir)^2   fs_conductor_reflectance, src/bdsf.c:84-91
+ * with the reference's own operations in the reference's order (IEEE division and multiplication give the same bits on the
+ * host as here), so with `paired` these return bit for bit what the functions above return: one division less per dielectric
+ * term, two less per conductor term. The pair's rows arrive in the registers of the inputs they replace: a dielectric's as
+ * (ir, tr, rel_sq in te's place), a conductor's as (cA in ir's place, cB in tr's). */
+__device__ __forceinline__ double dielectric_reflectance_sel(bool paired, double ir, double tr, double te_or_rel_sq, double inc_cos, double inc_sin_sq)
+{
+    double rel_sq = te_or_rel_sq;
+    if (!paired)
+    {
+        double rel = ir / tr;
+        rel_sq = rel * rel;
+    }
+    double ts_sin_sq = rel_sq * inc_sin_sq;
+    if (ts_sin_sq >= 1.0) return 1.0;
+    double ts_cos = __builtin_sqrt(1.0 - ts_sin_sq * ts_sin_sq);
+    double tr_on = tr * inc_cos;
+    double tr_ts = tr * ts_cos;
+    double ir_on = ir * inc_cos;
+    double ir_ts = ir * ts_cos;
+    double par = (tr_on - ir_ts) / (tr_on + ir_ts);
+    double per = (ir_on - tr_ts) / (ir_on + tr_ts);
+    par *= par;
+    per *= per;
+    return 0.5 * (par + per);
+}
+__device__ __forceinline__ double conductor_reflectance_sel(bool paired, double ir_or_cA, double tr_or_cB, double te, double inc_cos, double inc_cos_sq,
+                                                            double inc_sin_sq)
+{
+    double cA = ir_or_cA, cB = tr_or_cB;
+    if (!paired)
+    {
+        double rr = tr_or_cB / ir_or_cA;
+        double re = te / ir_or_cA;
+        double rr_sq = rr * rr;
+        double re_sq = re * re;
+        cA = rr_sq - re_sq;
+        cB = 4.0 * rr_sq * re_sq;
+    }
+    double r = cA - inc_sin_sq;
+    double apb_sq = __builtin_sqrt(r * r + cB);
+    double a = __builtin_sqrt(0.5 * (apb_sq + r));
+    double s = apb_sq + inc_cos_sq;
+    double t = 2.0 * a * inc_cos;
+    double u = inc_cos_sq * apb_sq + inc_sin_sq * inc_sin_sq;
+    double v = t * inc_sin_sq;
+    double par = (s - t) / (s + t);
+    double per = par * (u - v) / (u + v);
+    return 0.5 * (par + per);
+}
+
 /* ggx / ggx_att, src/bdsf.c:3-42 */
 __device__ __forceinline__ double ggx(V3 sn, V3 mn, double r)
 {

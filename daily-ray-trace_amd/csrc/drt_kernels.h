@@ -77,10 +77,18 @@ struct BvhLeafPrim
     double   pad;
 };             /* 64 bytes */
 
+/* Rows tabulated for a vertex's pair of media (drt_device.h, *_reflectance_sel), as bits 48-63 of record word 2:
+ * PAIR_NONE, or the first row's index (< 0x8000), with PAIR_CONDUCTOR set when the rows are a conductor's (cA, cB: two rows)
+ * and clear when they are a dielectric's (rel_sq: one row). A material gets rows only when its Fresnel functions are all of
+ * one kind, so the kind says which of the *_sel forms every function of the vertex's list takes. */
+#define PAIR_NONE 0xFFFFu
+#define PAIR_CONDUCTOR 0x8000u
 struct DevMaterial
 {
     uint32_t is_black_body, is_emissive, num_bdsfs, dir_func;
-    uint32_t needs, pad0;
+    uint32_t needs;
+    uint16_t pair_out, pair_in; /* the pair field for (incident = base material, transmit = this one) and for the other way round
+                                   (a ray leaving a sphere of this material) */
     int32_t  emission_spd, diffuse_spd, glossy_spd, mirror_spd, refract_spd, extinct_spd;
     double   shininess, roughness;
     double   refract_i0, refract_i1; /* refract_spd at the two samples around trans_wl (value_at_wl) */
@@ -135,7 +143,8 @@ struct DevCamera
 /*  vertex fixed part (10 words):                                                                  */
 /*     w0 = BDSF list, 4 bits per entry (the material's bdsfs[] in order)                          */
 /*     w1 = num_bdsfs (0-7) | sampled-direction flags (8-15) | diffuse SPD (16-31) | glossy SPD (32-47) | mirror SPD (48-63) */
-/*     w2 = incident refract SPD (0-15) | transmit refract SPD (16-31) | transmit extinct SPD (32-47) */
+/*     w2 = incident refract SPD (0-15) | transmit refract SPD (16-31) | transmit extinct SPD (32-47) |
+ *          rows tabulated for this pair of media (48-63: PAIR_NONE, or first row | PAIR_CONDUCTOR)                           */
 /*     w3 = on_dot, w4 = 1/pdf of the sampled direction                                            */
 /*     w5..w8 = |n.in|, glossy pow term, |n.m|, GGX coefficient (sampled direction), w9 unused      */
 /*  per light (6 words):                                                                           */
@@ -469,6 +478,31 @@ __device__ __forceinline__ void find_ray_intersection(const SceneView &sv, const
 __device__ __forceinline__ double refract_at_trans_wl(const DevScene &sc, const DevMaterial &m)
 {
     return drt_lerp(sc.trans_wl, sc.trans_w0, sc.trans_w1, m.refract_i0, m.refract_i1);
+}
+
+/* vertex record word 2: the SPD rows of the media either side of the hit, and the rows tabulated for that pair (if any) */
+__device__ __forceinline__ uint64_t record_media_word(const DevScene &sc, const SceneView &sv, const HitPoint &ip)
+{
+    const DevMaterial &sm = sv.mats[ip.surface_mat];
+    uint32_t pair = PAIR_NONE;
+    if (ip.incident_mat == sc.base_mat && ip.transmit_mat == ip.surface_mat) pair = sm.pair_out;
+    else if (ip.incident_mat == ip.surface_mat && ip.transmit_mat == sc.base_mat) pair = sm.pair_in;
+    return (uint64_t)((uint32_t)sv.mats[ip.incident_mat].refract_spd & 0xFFFFu) |
+           ((uint64_t)((uint32_t)sv.mats[ip.transmit_mat].refract_spd & 0xFFFFu) << 16) |
+           ((uint64_t)((uint32_t)sv.mats[ip.transmit_mat].extinct_spd & 0xFFFFu) << 32) | ((uint64_t)pair << 48);
+}
+/* which three table rows a vertex's per-wavelength Fresnel inputs come from: (ir, tr, te) as the reference has them, or --
+ * pair rows tabulated -- (ir, tr, rel_sq) for a dielectric and (cA, cB, -) for a conductor: same registers, same three loads */
+__device__ __forceinline__ void fresnel_rows(uint64_t w2, uint32_t &i0, uint32_t &i1, uint32_t &i2, bool &paired)
+{
+    const uint32_t i_ir = (uint32_t)(w2)&0xFFFFu, i_tr = (uint32_t)(w2 >> 16) & 0xFFFFu, i_te = (uint32_t)(w2 >> 32) & 0xFFFFu;
+    const uint32_t pair = (uint32_t)(w2 >> 48) & 0xFFFFu;
+    paired = pair != PAIR_NONE;
+    const bool conductor = paired && (pair & PAIR_CONDUCTOR) != 0u;
+    const uint32_t row = pair & (PAIR_CONDUCTOR - 1u);
+    i0 = conductor ? row : i_ir;
+    i1 = conductor ? row + 1u : i_tr;
+    i2 = (paired && !conductor) ? row : i_te;
 }
 
 /* The per-direction scalars of every BDSF in the material's list (src/bdsf.c:105-186):
@@ -1012,9 +1046,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
                 vrec[0] = mat.bdsf_packed;
                 vrec[1] = (uint64_t)mat.num_bdsfs | ((uint64_t)(e.flags | mat.vertex_flags) << 8) | ((uint64_t)((uint32_t)mat.diffuse_spd & 0xFFFFu) << 16) |
                           ((uint64_t)((uint32_t)mat.glossy_spd & 0xFFFFu) << 32) | ((uint64_t)((uint32_t)mat.mirror_spd & 0xFFFFu) << 48);
-                vrec[2] = (uint64_t)((uint32_t)sv.mats[ip.incident_mat].refract_spd & 0xFFFFu) |
-                          ((uint64_t)((uint32_t)sv.mats[ip.transmit_mat].refract_spd & 0xFFFFu) << 16) |
-                          ((uint64_t)((uint32_t)sv.mats[ip.transmit_mat].extinct_spd & 0xFFFFu) << 32);
+                vrec[2] = record_media_word(sc, sv, ip);
                 vrec[3] = (uint64_t)__double_as_longlong(ip.on_dot);
                 vrec[4] = (uint64_t)__double_as_longlong(dir_pdf);
                 store_coef(vrec + 5, e);
@@ -1121,9 +1153,11 @@ __device__ __forceinline__ double spd_at(SpdPtr spds, uint32_t S, uint32_t idx, 
 
 /* One BDSF sum for one wavelength: bdsf(), src/daily_ray_trace.c:215-229. `bdsf_result` is zeroed
  * once and carried from function to function; functions whose direction test fails leave it (Q1). */
+/* `paired`: the vertex's pair of media has tabulated rows (fresnel_rows): then te is rel_sq for the dielectric functions, and
+ * (ir, tr) are (cA, cB) for the conductor functions -- the *_sel forms of drt_device.h, same bits with fewer divisions. */
 __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num_bdsfs, double diffuse_pi, double glossy, double mirror,
                                                      double ir, double tr, double te, double on_dot, double a_in, double spec,
-                                                     double mn_dot, double ct_coef, uint32_t flags)
+                                                     double mn_dot, double ct_coef, uint32_t flags, bool paired)
 {
     double bdsf_result = 0.0;
     double reflectance = 0.0;
@@ -1149,28 +1183,28 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
                 {
                     DRT_PIN_HERE(ir);
                     double c2 = on_dot * on_dot;
-                    bdsf_result = conductor_reflectance(ir, tr, te, on_dot, c2, 1.0 - c2);
+                    bdsf_result = conductor_reflectance_sel(paired, ir, tr, te, on_dot, c2, 1.0 - c2);
                 }
                 break;
             case DRT_BDSF_fs_dielectric_reflectance_bdsf: /* :148-159 */
                 if (flags & FLAG_EQR)
                 {
                     DRT_PIN_HERE(ir);
-                    bdsf_result = dielectric_reflectance(ir, tr, on_dot, 1.0 - on_dot * on_dot);
+                    bdsf_result = dielectric_reflectance_sel(paired, ir, tr, te, on_dot, 1.0 - on_dot * on_dot);
                 }
                 break;
             case DRT_BDSF_fs_dielectric_transmittance_bdsf: /* :161-172, :69-76 */
                 if (flags & FLAG_EQT)
                 {
                     DRT_PIN_HERE(ir);
-                    bdsf_result = 1.0 - dielectric_reflectance(ir, tr, on_dot, 1.0 - on_dot * on_dot);
+                    bdsf_result = 1.0 - dielectric_reflectance_sel(paired, ir, tr, te, on_dot, 1.0 - on_dot * on_dot);
                 }
                 break;
             case DRT_BDSF_ct_conductor_bdsf: /* :174-186 */
             {
                 DRT_PIN_HERE(ir);
                 double c2 = mn_dot * mn_dot;
-                bdsf_result = conductor_reflectance(ir, tr, te, mn_dot, c2, 1.0 - c2) * ct_coef;
+                bdsf_result = conductor_reflectance_sel(paired, ir, tr, te, mn_dot, c2, 1.0 - c2) * ct_coef;
                 break;
             }
             default: break;
@@ -1353,8 +1387,10 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
                 const uint32_t i_diffuse = (uint32_t)(w1 >> 16) & 0xFFFFu, i_glossy = (uint32_t)(w1 >> 32) & 0xFFFFu;
                 const double diffuse_pi = spd_at(table, S, i_diffuse, lam), glossy = spd_at(table, S, i_glossy, lam);
                 const double mirror = spd_at(table, S, (uint32_t)(w1 >> 48) & 0xFFFFu, lam);
-                const double ir = spd_at(table, S, (uint32_t)(w2)&0xFFFFu, lam), tr = spd_at(table, S, (uint32_t)(w2 >> 16) & 0xFFFFu, lam);
-                const double te = spd_at(table, S, (uint32_t)(w2 >> 32) & 0xFFFFu, lam);
+                uint32_t f0, f1, f2;
+                bool paired;
+                fresnel_rows(w2, f0, f1, f2, paired);
+                const double ir = spd_at(table, S, f0, lam), tr = spd_at(table, S, f1, lam), te = spd_at(table, S, f2, lam);
                 double contribution = 0.0;
                 for (uint32_t l = 0; l < sp.n_lights; l += 1)
                 {
@@ -1364,14 +1400,14 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
                     if (!(lflags & FLAG_VISIBLE)) continue;
                     double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse_pi, glossy, mirror, ir, tr, te, on_dot,
                                                             word_as_double(lrec[2]), word_as_double(lrec[3]), word_as_double(lrec[4]),
-                                                            word_as_double(lrec[5]), lflags);
+                                                            word_as_double(lrec[5]), lflags, paired);
                     contribution = contribution + reflectance;
                     contribution = contribution * spd_at(table, S, (uint32_t)(lw0 & 0xFFFFu), lam);
                     contribution = contribution * word_as_double(lrec[1]);
                 }
                 dst = dst + throughput * contribution;
                 double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse_pi, glossy, mirror, ir, tr, te, on_dot, s_a_in, s_spec,
-                                                        word_as_double(vrec[7]), word_as_double(vrec[8]), sflags);
+                                                        word_as_double(vrec[7]), word_as_double(vrec[8]), sflags, paired);
                 reflectance = reflectance * dir_pdf;
                 throughput = throughput * reflectance;
                 v += 1;
@@ -1844,7 +1880,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                 const uint32_t sflags = (uint32_t)(w1 >> 8) & 0xFFu;
                 const uint32_t i_diffuse = (uint32_t)(w1 >> 16) & 0xFFFFu, i_glossy = (uint32_t)(w1 >> 32) & 0xFFFFu;
                 const uint32_t i_mirror = (uint32_t)(w1 >> 48) & 0xFFFFu;
-                const uint32_t i_ir = (uint32_t)(w2)&0xFFFFu, i_tr = (uint32_t)(w2 >> 16) & 0xFFFFu, i_te = (uint32_t)(w2 >> 32) & 0xFFFFu;
+                uint32_t i_ir, i_tr, i_te; /* or the pair's rows in their place */
+                bool paired;               /* wave-uniform: the record word came through v_readlane */
+                fresnel_rows(w2, i_ir, i_tr, i_te, paired);
                 const double s_a_in = word_as_double(readlane64(src, lane0 + 5)), s_spec = word_as_double(readlane64(src, lane0 + 6));
 
                 if (sflags & FLAG_PLASTIC) /* a plastic vertex beyond the header's 16 flags */
@@ -1887,7 +1925,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                     {
                         double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse[k], glossy[k], mirror[k], ir[k], tr[k], te[k], on_dot,
                                                                 word_as_double(lw[2]), word_as_double(lw[3]), word_as_double(lw[4]),
-                                                                word_as_double(lw[5]), lflags);
+                                                                word_as_double(lw[5]), lflags, paired);
                         contribution[k] = contribution[k] + reflectance;                      /* :323 */
                         contribution[k] = contribution[k] * spd_at(table, S, i_em, lam_c[k]); /* :324 */
                         contribution[k] = contribution[k] * c;                                /* :326-327 */
@@ -1899,7 +1937,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                 {
                     dst[k] = dst[k] + throughput[k] * contribution[k]; /* :461-462 */
                     double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse[k], glossy[k], mirror[k], ir[k], tr[k], te[k], on_dot,
-                                                            s_a_in, s_spec, s_mn, s_ct, sflags);
+                                                            s_a_in, s_spec, s_mn, s_ct, sflags, paired);
                     reflectance = reflectance * dir_pdf;         /* :468 */
                     throughput[k] = throughput[k] * reflectance; /* :469 */
                 }

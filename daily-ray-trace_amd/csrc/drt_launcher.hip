@@ -454,7 +454,25 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene, double r
         for (uint32_t i = 0; i < scene->num_materials; i += 1)
             if (scene->materials[i].diffuse_spd >= 0 && !seen[scene->materials[i].diffuse_spd]++) n_diffuse += 1;
     }
-    const uint32_t zero_row = scene->num_spds + n_diffuse;
+    /* Rows tabulated per pair of media for the Fresnel terms (drt_device.h, *_reflectance_sel; drt_kernels.h, PAIR_*): a material
+     * whose list holds dielectric Fresnel functions gets one row (rel_sq) for rays entering it from the base material and one for
+     * rays leaving it; one that holds conductor functions two rows (cA, cB) for rays arriving from the base material. A list
+     * with both kinds gets none (the shade kernel tells the kind from the pair field, not per function). */
+    auto fresnel_kind = [&](const drt_material &m) -> int { /* 0 none or mixed, 1 dielectric, 2 conductor */
+        bool d = false, c = false;
+        for (uint32_t j = 0; j < std::min<uint32_t>(m.num_bdsfs, DRT_MAX_BDSFS); j += 1)
+        {
+            const uint32_t b = m.bdsfs[j];
+            d = d || b == DRT_BDSF_fs_dielectric_reflectance_bdsf || b == DRT_BDSF_fs_dielectric_transmittance_bdsf;
+            c = c || b == DRT_BDSF_fs_conductor_bdsf || b == DRT_BDSF_ct_conductor_bdsf;
+        }
+        if (getenv("DRT_NO_PAIR_ROWS")) return 0; /* A/B knob of the parity tests: every term from ir, tr, te */
+        return (d && !c) ? 1 : (c && !d) ? 2 : 0;
+    };
+    uint32_t n_pair_rows = 0;
+    for (uint32_t i = 0; i < scene->num_materials; i += 1) n_pair_rows += 2u * (uint32_t)(fresnel_kind(scene->materials[i]) != 0);
+    const uint32_t zero_row = scene->num_spds + n_diffuse + n_pair_rows;
+    if (zero_row >= PAIR_CONDUCTOR) n_pair_rows = 0; /* row numbers must fit below the kind bit: (never with real scenes) no pair rows then */
     std::vector<DevMaterial> mats(scene->num_materials);
     for (uint32_t i = 0; i < scene->num_materials; i += 1)
     {
@@ -505,6 +523,37 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene, double r
             if (b == DRT_BDSF_ct_conductor_bdsf) dm.needs |= NEED_CT;
         }
         if (dm.num_bdsfs == 2 && dm.bdsfs[0] == DRT_BDSF_bp_diffuse_bdsf && dm.bdsfs[1] == DRT_BDSF_bp_glossy_bdsf) dm.vertex_flags = FLAG_PLASTIC;
+        dm.pair_out = dm.pair_in = PAIR_NONE;
+        const int kind = n_pair_rows ? fresnel_kind(m) : 0;
+        if (kind)
+        {
+            /* a spectrum that is not given reads as zeros, as everywhere (the table's all-zero row) */
+            const drt_material &bm = scene->materials[scene->base_material];
+            auto at = [&](int32_t spd, uint32_t k) { return spd >= 0 ? scene->spds[(size_t)spd * S + k] : 0.0; };
+            const uint32_t r0 = (uint32_t)(spds.size() / S);
+            if (kind == 1)
+            {
+                /* rel_sq = (ir / tr) (ir / tr), src/bdsf.c:52-56: entering (ir the base material's, tr this one's), then leaving */
+                for (uint32_t k = 0; k < S; k += 1) { const double rel = at(bm.refract_spd, k) / at(m.refract_spd, k); spds.push_back(rel * rel); }
+                for (uint32_t k = 0; k < S; k += 1) { const double rel = at(m.refract_spd, k) / at(bm.refract_spd, k); spds.push_back(rel * rel); }
+                dm.pair_out = (uint16_t)r0;
+                dm.pair_in = (uint16_t)(r0 + 1u);
+            }
+            else
+            {
+                /* cA = rr_sq - re_sq, cB = 4 rr_sq re_sq with rr = tr / ir, re = te / ir, src/bdsf.c:84-91 */
+                std::vector<double> cB(S);
+                for (uint32_t k = 0; k < S; k += 1)
+                {
+                    const double ir = at(bm.refract_spd, k), rr = at(m.refract_spd, k) / ir, re = at(m.extinct_spd, k) / ir;
+                    const double rr_sq = rr * rr, re_sq = re * re;
+                    spds.push_back(rr_sq - re_sq);
+                    cB[k] = 4.0 * rr_sq * re_sq;
+                }
+                spds.insert(spds.end(), cB.begin(), cB.end());
+                dm.pair_out = (uint16_t)(r0 | PAIR_CONDUCTOR);
+            }
+        }
         if (!m.is_black_body && dm.dir_func >= DRT_NUM_DIRFS) return fail(-2, "material %u: unknown dir_func id %u", i, dm.dir_func);
     }
     spds.resize((size_t)(zero_row + 1) * S, 0.0); /* + the all-zero row */

@@ -1218,3 +1218,35 @@ def test_rccl_one_rank_gather_of_a_film_block():
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "RCCL_OK nccl" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("name", ["plane_light_48", "gold_mirror", "grid_4nm", "grid_2p5nm", "many_lights"])
+def test_fresnel_rows_tabulated_per_pair_of_media_change_no_bit(name, monkeypatch):
+    """The launcher tabulates, per wavelength and pair of media, the quotients the Fresnel terms start from -- (ir/tr)^2 for glass,
+    (tr/ir)^2 - (te/ir)^2 and 4 (tr/ir)^2 (te/ir)^2 for gold -- with the reference's own operations, and the shade kernel reads them
+    instead of dividing per vertex. DRT_NO_PAIR_ROWS=1 turns the table off: film, XYZ, hits and statistics are the same bit for bit
+    (main pass and tail pass, one and several wavelength sets, spectral and XYZ film)."""
+    bundle, params = cases.load_case(name)
+    for mode in (pydrt.MODE_SPECTRAL, pydrt.MODE_XYZ):
+        p = pydrt.make_params(int(params.width), int(params.height), spp=int(params.spp), max_depth=int(params.max_depth), seed=int(params.seed),
+                              pixel_scheme=int(params.pixel_scheme), mode=mode)
+        monkeypatch.delenv("DRT_NO_PAIR_ROWS", raising=False)
+        a = _render_all(bundle, p)
+        monkeypatch.setenv("DRT_NO_PAIR_ROWS", "1")
+        b = _render_all(bundle, p)
+        monkeypatch.delenv("DRT_NO_PAIR_ROWS")
+        assert all(np.array_equal(x, y) for x, y in zip(a[0], b[0])), (name, mode)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and _counts(a[3]) == _counts(b[3])
+        assert float(np.abs(a[0][0]).sum()) > 0.0
+
+
+@pytest.mark.parametrize("seed", [3, 7, 12, 19, 23, 31, 40, 44, 101, 104])
+def test_fresnel_rows_on_random_scenes_with_nested_media(seed, monkeypatch):
+    """The same A/B on random scenes: overlapping glass / dense / gold spheres give vertices whose pair of media is NOT (base
+    material, surface material) -- those keep the per-vertex divisions -- next to vertices that use the table; NaN for NaN."""
+    bundle, params = fuzz_scenes.load(seed, pydrt)
+    a = _render_all(bundle, params)
+    monkeypatch.setenv("DRT_NO_PAIR_ROWS", "1")
+    b = _render_all(bundle, params)
+    monkeypatch.delenv("DRT_NO_PAIR_ROWS")
+    assert all(fuzz_scenes.same(x, y) for x, y in zip(a[0], b[0])) and np.array_equal(a[1], b[1]) and _counts(a[3]) == _counts(b[3])
