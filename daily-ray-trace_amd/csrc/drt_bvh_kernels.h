@@ -425,12 +425,13 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
 
     uint32_t n_scans = 0, n_shaded = 0, n_shadow = 0, n_draws = 0;
 
-    /* per-lane path state. A path is either AT A VERTEX (ip valid; lights [0, light) done) or ON A RAY (ro, rd; no vertex yet). */
+    /* per-lane path state. A path is either AT A VERTEX (ip valid; lights [0, light) done) or ON A RAY with no vertex yet -- and then
+     * the ray lives in ip's registers, origin in ip.position (it IS the vertex the ray leaves, src/daily_ray_trace.c:471) and
+     * direction in ip.out: the two states never need both, and the kernel is short of registers. */
     bool alive = false, at_vertex = false;
     uint64_t rs = 1, hit_row = 0;
     uint32_t depth = 0, shaded = 0, light = 0;
-    uint32_t vis0_mask = 0, plastic_mask = 0;
-    V3 ro = v3(0, 0, 0), rd = v3(0, 0, 0);
+    uint32_t masks = 0; /* bits 0-15: shaded vertex v has the two-lobe plastic list; bits 16-23: light 0 is visible from vertex v (header bits 48-63, 24-31) */
     uint64_t *hdr = nullptr;
     uint32_t blk = 0, tbl = 0; /* the pool block of the current pair of vertices; the path's table block (deep paths) */
     uint32_t spare = ~0u, spare_tbl = ~0u; /* a block (and, for deep paths, a table block) held ready: path_spare_block */
@@ -502,6 +503,7 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
                 hit_row = ps.hit_row;
                 rs = drt_splitmix64(path_key(tp, ps));
                 uint32_t camera_draws = 0; /* counted by the primary kernel */
+                V3 ro, rd;
                 camera_ray(cam, tp.pixel_scheme, ps.x, ps.y, rs, camera_draws, ro, rd);
                 hdr = headers + ps.slot * REC_HEADER_WORDS;
                 const PrimaryHit ph = primary[ps.slot];
@@ -509,8 +511,7 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
                 depth = 0;
                 shaded = 0;
                 light = 0;
-                plastic_mask = 0;
-                vis0_mask = 0;
+                masks = 0;
                 alive = true;
                 at_vertex = true;
                 new_vertex = true;
@@ -532,16 +533,16 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
         int job = JOB_NONE;
         V3 jo = v3(0, 0, 0), jd = v3(0, 0, 1);
         double limit = DRT_INF;
-        V3 light_position = v3(0, 0, 0);
-        double attenuation = 1.0, light_pdf = 1.0;
+        double light_c = 1.0; /* attenuation x area of the light sample, :326 */
         if (alive && at_vertex && light < sv.n_lights)
         {
             /* direct_light_contribution, src/daily_ray_trace.c:272-332: the sample of light `light` (drawn before the shadow test) */
             const uint32_t l = light;
             const uint32_t ltype = sv.light_type[l];
             const V3 lpos = v3(sv.lights[LF_PX * sv.n_lights + l], sv.lights[LF_PY * sv.n_lights + l], sv.lights[LF_PZ * sv.n_lights + l]);
-            light_pdf = sv.lights[LF_PDF * sv.n_lights + l];
-            light_position = lpos;
+            const double light_pdf = sv.lights[LF_PDF * sv.n_lights + l];
+            double attenuation = 1.0;
+            V3 light_position = lpos;
             if (ltype == DRT_GEO_POINT)
             {
                 double dist = v_length(v_sub(light_position, ip.position));
@@ -571,12 +572,13 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
             jd = v_normalise(v_sub(light_position, ip.position));
             jo = v_sum(ip.position, v_mul(jd, DRT_VIS_FUDGE));
             limit = v_length(v_sub(light_position, jo)) - DRT_VIS_FUDGE;
+            light_c = attenuation * (light_pdf);
             job = JOB_SHADOW;
         }
         else if (alive && !at_vertex)
         {
-            jo = v_sum(ro, v_mul(rd, DRT_VIS_FUDGE)); /* :339 */
-            jd = rd;
+            jd = ip.out; /* on a ray: its direction, and its origin in ip.position */
+            jo = v_sum(ip.position, v_mul(jd, DRT_VIS_FUDGE)); /* :339 */
             job = JOB_CLOSEST;
         }
         int index = -1;
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
             {
                 const uint32_t term = mat.is_emissive ? 1u : 0u;
                 const uint32_t term_spd = mat.is_emissive ? ((uint32_t)mat.emission_spd & 0xFFFFu) : 0u;
-                hdr[0] = (uint64_t)shaded | ((uint64_t)term << 16) | ((uint64_t)term_spd << 32) | ((uint64_t)plastic_mask << 48) | ((uint64_t)vis0_mask << 24);
+                hdr[0] = (uint64_t)shaded | ((uint64_t)term << 16) | ((uint64_t)term_spd << 32) | ((uint64_t)(masks & 0xFFFFu) << 48) | ((uint64_t)(masks >> 16) << 24);
                 alive = false;
             }
             else
@@ -619,12 +621,12 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
             uint32_t lflags = 0;
             if (!occluded)
             {
-                V3 incoming = v_normalise(v_sub(light_position, ip.position));
-                EvalCoef e = eval_coefficients(sc, sv, ip, incoming);
+                /* incoming = normalise(light_position - position), :320: the very expression (same operands, same operations) that gave
+                 * the shadow ray its direction, :241 -- so it is jd, bit for bit, and the light's position need not stay live */
+                EvalCoef e = eval_coefficients(sc, sv, ip, jd);
                 lflags = e.flags | FLAG_VISIBLE;
-                if (l == 0 && shaded < 8u) vis0_mask |= 1u << shaded;
-                double c = attenuation * (light_pdf);
-                lrec[1] = (uint64_t)__double_as_longlong(c);
+                if (l == 0 && shaded < 8u) masks |= 0x10000u << shaded;
+                lrec[1] = (uint64_t)__double_as_longlong(light_c);
                 store_coef(lrec + 2, e);
             }
             uint32_t em_spd = (uint32_t)sv.mats[sv.light_mat[l]].emission_spd & 0xFFFFu;
@@ -652,15 +654,14 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
             vrec[3] = (uint64_t)__double_as_longlong(ip.on_dot);
             vrec[4] = (uint64_t)__double_as_longlong(dir_pdf);
             store_coef(vrec + 5, e);
-            if ((mat.vertex_flags & FLAG_PLASTIC) && shaded < 16u) plastic_mask |= 1u << shaded;
+            if ((mat.vertex_flags & FLAG_PLASTIC) && shaded < 16u) masks |= 1u << shaded;
             shaded += 1;
-            rd = in;
-            ro = ip.position;
+            ip.out = in; /* the path is on a ray again: from ip.position along `in` */
             depth += 1;
             at_vertex = false;
             if (depth >= tp.max_depth)
             {
-                hdr[0] = (uint64_t)shaded | ((uint64_t)plastic_mask << 48) | ((uint64_t)vis0_mask << 24);
+                hdr[0] = (uint64_t)shaded | ((uint64_t)(masks & 0xFFFFu) << 48) | ((uint64_t)(masks >> 16) << 24);
                 alive = false;
             }
         }
