@@ -231,12 +231,6 @@ __global__ __launch_bounds__(PRIMARY_BLOCK) void drt_primary_kernel(DevScene sc,
 /* Bounces: one traversal job per lane and iteration                                                */
 
 #define BOUNCE_BLOCK 256
-#ifndef DRT_BOUNCE_IN_STEP
-#define DRT_BOUNCE_IN_STEP 1
-#endif
-#ifndef DRT_BVH_ONE_PER_LEAF
-#define DRT_BVH_ONE_PER_LEAF 1 /* the builder puts one surface in a leaf (BvhBuilder::LEAF): the bounce kernel's leaf step is no loop */
-#endif
 #ifndef DRT_BOUNCE_WAVES_PER_SIMD
 #define DRT_BOUNCE_WAVES_PER_SIMD 3
 #endif
@@ -255,9 +249,7 @@ __device__ __forceinline__ int stack_pop(const int *stack, uint32_t lane, int &s
     return BVH_DONE;
 }
 
-#ifndef DRT_BVH_POSTPONE
 #define DRT_BVH_POSTPONE 4 /* leaves a lane may put aside before it has to wait for the wave's leaf phase (0: the plain while-while walk) */
-#endif
 #ifndef DRT_BVH_POSTPONE_EXIT
 #define DRT_BVH_POSTPONE_EXIT 16 /* the node phase ends when fewer lanes than this are still walking and one of the others waits with a full queue */
 #endif
@@ -289,7 +281,6 @@ __device__ __forceinline__ void bvh_walk(const SceneView &sv, int *stack, int *l
     float lim = bvh_limit32(limit);
     int sp = 0;
     int cur = job == JOB_NONE ? BVH_DONE : 0;
-#if DRT_BVH_POSTPONE > 0
     /* "While-while" with leaves PUT ASIDE. In the plain form every lane walks inner nodes until it holds a leaf, and the distance to
      * the next leaf is so uneven from lane to lane (a handful of nodes on average, fifteen for the unluckiest of 64) that three
      * lanes in four wait. Here a lane that reaches a leaf notes it in a small queue of its own (LDS, DRT_BVH_POSTPONE entries) and
@@ -359,47 +350,6 @@ __device__ __forceinline__ void bvh_walk(const SceneView &sv, int *stack, int *l
                 }
             }
     }
-#else
-    for (;;)
-    {
-        while (cur >= 0) bvh_node_step(sv, stack, lane, r32, lim, cur, sp); /* inner nodes, until the lane holds a leaf */
-        if (!__any(cur != BVH_DONE)) break;
-        while (bvh_is_leaf(cur)) /* leaves, the wave together */
-        {
-            /* the whole 64-byte record at once: the centre test below wants its last quarter, the intersector (most lanes' next
-             * step) its first three, and fetched as they are needed that would be three round trips to L2 */
-            const BvhLeafPrim *src = &sv.bvh_leaf[(-2 - cur) >> 3];
-            BvhLeafPrim lp;
-            lp.index = src->index; lp.type = src->type;
-            lp.f[0] = src->f[0]; lp.f[1] = src->f[1]; lp.f[2] = src->f[2]; lp.f[3] = src->f[3];
-            lp.c32[0] = src->c32[0]; lp.c32[1] = src->c32[1]; lp.c32[2] = src->c32[2]; lp.reach32 = src->reach32;
-            __asm__ volatile("" : "+v"(lp.index), "+v"(lp.type), "+v"(lp.f[0]), "+v"(lp.f[1]), "+v"(lp.f[2]), "+v"(lp.f[3]));
-            bool stop = false;
-            if (!sphere_certainly_missed(lp, r32, lim))
-            {
-                double dist = leaf_distance(sv, lp, o, d);
-                if (job == JOB_CLOSEST)
-                {
-                    if (dist < limit || (dist == limit && (int)lp.index < index))
-                    {
-                        limit = dist;
-                        index = (int)lp.index;
-                        lim = bvh_limit32(limit);
-                    }
-                }
-                else if (dist < limit) stop = true; /* the reference breaks at the first occluder; which one does not matter */
-            }
-            if (stop)
-            {
-                occluded = true;
-                sp = 0;
-                cur = BVH_DONE;
-            }
-            else cur = stack_pop(stack, lane, sp);
-        }
-        if (!__any(cur != BVH_DONE)) break;
-    }
-#endif
 }
 
 __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_bounce_kernel(
@@ -448,20 +398,14 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
      * at the start of that cycle. Then an iteration runs the sections of ONE kind of job with every live lane in them and skips the
      * others (their branches see no lane), instead of all of them half empty; a lane whose path ends waits for the cycle's start,
      * at most one iteration with one light. */
-#if DRT_BOUNCE_IN_STEP
     const uint32_t cycle = sv.n_lights + 1u;
     uint32_t phase = 0;
-#endif
     for (;;)
     {
         /* ---- refill idle lanes from the queue of paths whose first vertex is known ---- */
         unsigned long long idle_mask = __ballot(!alive);
-#if DRT_BOUNCE_IN_STEP
         if (!exhausted && idle_mask == ~0ull) phase = 0; /* nobody left to stay in step with */
         if (idle_mask != 0ull && !exhausted && phase == 0u)
-#else
-        if (idle_mask != 0ull && !exhausted)
-#endif
         {
             const uint32_t want = (uint32_t)__popcll(idle_mask);
             const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
@@ -519,9 +463,7 @@ __global__ __launch_bounds__(BOUNCE_BLOCK, DRT_BOUNCE_WAVES_PER_SIMD) void drt_b
             }
         }
         if (!__any(alive)) break;
-#if DRT_BOUNCE_IN_STEP
         phase = phase + 1u == cycle ? 0u : phase + 1u;
-#endif
         /* a spare record block for the lanes whose path may open one at its next vertex (the whole wave takes part) */
         if (!path_spare_block(tp, wp, alive, shaded, spare, spare_tbl, lane))
         {

@@ -688,9 +688,6 @@ __device__ __forceinline__ void camera_ray(const DevCamera &cam, uint32_t scheme
 /* The trace kernel                                                                                */
 
 #define TRACE_BLOCK 256
-#ifndef DRT_TRACE_PIXEL_MAJOR
-#define DRT_TRACE_PIXEL_MAJOR 1 /* path ids run over the samples of a pixel first: a wave starts on 64 nearly identical rays (trace 73.0 -> 68.4 ms) */
-#endif
 #ifndef DRT_TRACE_WAVES_PER_SIMD
 #define DRT_TRACE_WAVES_PER_SIMD 3 /* register budget: launch_bounds' 2nd argument is waves per SIMD */
 #endif
@@ -855,13 +852,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
             bool started = alive && ((idle_mask >> lane) & 1ull);
             if (started)
             {
-#if DRT_TRACE_PIXEL_MAJOR
                 uint64_t q = pid / tp.n_samples; /* consecutive ids: the samples of one pixel */
                 uint64_t s_local = pid - q * tp.n_samples;
-#else
-                uint64_t s_local = pid / tp.n_pix; /* consecutive ids: neighbouring pixels of one sample */
-                uint64_t q = pid - s_local * tp.n_pix;
-#endif
                 hit_row = s_local * tp.n_pix + q;
                 uint32_t j = (uint32_t)(q / tp.tile_w);
                 uint32_t i = (uint32_t)(q - (uint64_t)j * tp.tile_w);
@@ -1231,20 +1223,9 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
 #ifndef SHADE_PREFETCH_REGS
 #define SHADE_PREFETCH_REGS 2 /* 64-word registers per path: 128 record words are prefetched, deeper paths fall back */
 #endif
-#ifndef SHADE_PREFETCH_DEPTH
 #define SHADE_PREFETCH_DEPTH 1 /* samples whose record loads are in flight ahead of the one being replayed. Latency is hidden by the other
                                   waves at any depth (the kernel is bound by what it issues); one ahead is the fewest
                                   register moves and LDS writes: 106.0 ms against 106.8 with two */
-#endif
-#ifndef DRT_SHADE_DEEP_BLOCKS
-#define DRT_SHADE_DEEP_BLOCKS 1 /* plastic runs continue past the prefetched records, a block (four vertices) per load */
-#endif
-#ifndef DRT_SHADE_PLASTIC_RUN
-#define DRT_SHADE_PLASTIC_RUN 1 /* the leading plastic vertices of a path in a loop of their own (one light, one set) */
-#endif
-#ifndef DRT_SHADE_LDS_WORDS
-#define DRT_SHADE_LDS_WORDS 1 /* plastic vertices read their coefficient words from LDS (broadcast loads) instead of v_readlane pairs */
-#endif
 #define SHADE_PIXEL_CHUNK 16 /* pixels per group when there is no tail pass (with one: 64 / tail wavelengths) */
 
 #define XYZ_FILM_WORDS 8 /* XYZ film mode, per pixel: X, Y, Z numerators of the main pass, filter sum, X, Y, Z of the tail pass, unused */
@@ -1494,10 +1475,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
-#if DRT_SHADE_LDS_WORDS
     /* behind the SPD table: two record slots per wave (see the sample loop) */
     uint64_t *rec_lds = (uint64_t *)(lds + (SPDS_IN_LDS ? (size_t)sc.n_spd * S : 0)) + (size_t)(threadIdx.x >> 6) * (2u * 64u * SHADE_PREFETCH_REGS);
-#endif
     const uint32_t vw = sp.vertex_words;                 /* power of two >= 16 */
     const uint32_t vpr = vw <= 64 ? 64u / vw : 0u;       /* vertices per 64-word register (0: records wider than a register) */
     const uint32_t n_fast_regs = vpr * SHADE_PREFETCH_REGS;
@@ -1640,32 +1619,16 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                 prefetch(sa < n_win ? sa : 0u, nw, ring[SHADE_PREFETCH_DEPTH]);
             }
             const uint64_t *cur = ring[0];
-#if DRT_SHADE_LDS_WORDS
-            /* The records of the sample AFTER this one (requested a sample ago) go to this wave's LDS slot (s + 1) & 1: the
-             * coefficient words of a plastic vertex are then read back as broadcast LDS loads -- one instruction per 64-bit word,
-             * result in a vector register where the f64 operations want it -- instead of two v_readlane each. */
-#if SHADE_PREFETCH_DEPTH <= 1
+            /* This sample's records (requested a sample ago) also go to this wave's LDS slot s & 1: the coefficient words of a
+             * plastic vertex are then read back as broadcast LDS loads -- one instruction per 64-bit word, result in a vector
+             * register where the f64 operations want it -- instead of two v_readlane each. */
             if (n_shaded != 0u)
             {
-                /* one sample ahead: the slot gets THIS sample's records (the next one's are still on their way) */
                 uint64_t *slot_now = rec_lds + (s & 1u) * (64u * SHADE_PREFETCH_REGS);
 #pragma unroll
                 for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) slot_now[64u * k + lane] = ring[0][k];
             }
-#else
-            {
-                uint64_t *slot_next = rec_lds + ((s + 1u) & 1u) * (64u * SHADE_PREFETCH_REGS);
-#pragma unroll
-                for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) slot_next[64u * k + lane] = ring[1][k];
-                if (s == 0)
-                {
-#pragma unroll
-                    for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) rec_lds[64u * k + lane] = ring[0][k];
-                }
-            }
-#endif
             const uint64_t *rec_words = rec_lds + (s & 1u) * (64u * SHADE_PREFETCH_REGS);
-#endif
 
             double throughput[NSETS], dst[NSETS];
 #pragma unroll
@@ -1675,7 +1638,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                 dst[k] = 0.0;
             }
             uint32_t v_first = 0; /* vertices [0, v_first) are done by the loop for plastic runs below */
-#if DRT_SHADE_LDS_WORDS && DRT_SHADE_PLASTIC_RUN
             if (NSETS == 1 && sp.n_lights == 1u && vpr != 0u)
             {
                 /* The path's leading run of two-lobe plastic vertices -- most paths are nothing else -- in a loop of its own: the header's
@@ -1722,7 +1684,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                 for (uint32_t v = run0; v < run; v += 1)
                     run_vertex(readlane64(cur[SHADE_PREFETCH_REGS > 1 ? 1 : 0], (v - vpr) * vw + 1u), rec_words + v * vw, ((vis0_mask >> v) & 1u) != 0u);
                 v_first = run;
-#if DRT_SHADE_DEEP_BLOCKS
                 /* Beyond the prefetched records (vertices 8 and up: long paths in closed scenes), when everything so far was a run: the
                  * path's further blocks one at a time -- four vertices by ONE coalesced load, which takes the place of vertices 0-3
                  * in this sample's LDS slot, then the same loop (visibility from the light's flag word, the header has 8 bits). A
@@ -1751,10 +1712,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                         if (v < v_hi) break; /* something else than plastic: the general loop takes over */
                     }
                 }
-#endif
                 }
             }
-#endif
             for (uint32_t v = v_first; v < n_shaded; v += 1)
             {
                 /* the register (and the lane offset in it) that holds this vertex's record */
@@ -1797,13 +1756,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                             if ((vis0_mask >> v) & 1u)
                             {
                                 const uint32_t off = REC_VERTEX_WORDS;
-#if DRT_SHADE_LDS_WORDS
                                 const uint64_t *lw = rec_words + v * vw + off;
                                 const double c = word_as_double(lw[1]), a_in = word_as_double(lw[2]), spec = word_as_double(lw[3]);
-#else
-                                const double c = word_as_double(readlane64(src, lane0 + off + 1));
-                                const double a_in = word_as_double(readlane64(src, lane0 + off + 2)), spec = word_as_double(readlane64(src, lane0 + off + 3));
-#endif
 #pragma unroll
                                 for (int k = 0; k < NSETS; k += 1)
                                 {
@@ -1858,14 +1812,12 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                 if (v < 16u && ((plastic_mask >> v) & 1u))
                 {
                     const uint64_t w1p = readlane64(src, lane0 + 1);
-#if DRT_SHADE_LDS_WORDS
                     if (v < n_fast)
                     {
                         const uint64_t *vwords = rec_words + v * vw;
                         plastic_vertex(w1p, word_as_double(vwords[4]), word_as_double(vwords[5]), word_as_double(vwords[6]));
                         continue;
                     }
-#endif
                     const double dir_pdf_p = word_as_double(readlane64(src, lane0 + 4));
                     const double s_a_in_p = word_as_double(readlane64(src, lane0 + 5)), s_spec_p = word_as_double(readlane64(src, lane0 + 6));
                     plastic_vertex(w1p, dir_pdf_p, s_a_in_p, s_spec_p);

@@ -195,7 +195,7 @@ struct BvhBuilder
     std::vector<BuildPrim> prims;
     std::vector<BvhNode>   nodes;
     std::vector<uint32_t>  order;
-    int LEAF = 1; /* surfaces per leaf (the traversal packs a count <= 8 in 3 bits, but the bounce kernel is built for one: DRT_BVH_ONE_PER_LEAF).
+    int LEAF = 1; /* surfaces per leaf: ONE, which is what the kernels' leaf steps are written for (the reference packs a count <= 8 in 3 bits).
                      Config 5, trace stage: 757 ms with 1, 855 with 2, 948 with 4 */
     int max_depth = 0;    /* deepest level holding a node: the traversal pushes at most one entry per level */
     double pad32 = 0.0;   /* extra padding of the STORED boxes that pays for testing them in f32 (drt_kernels.h, Ray32) */
@@ -838,7 +838,7 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     }
     /* shade kernel LDS: SPD tables + two record buffers per wave */
     ctx->shade_lds = ctx->spds_in_lds ? (size_t)ctx->dsc.n_spd * S * 8 : 0;
-    if (DRT_SHADE_LDS_WORDS) ctx->shade_lds += (size_t)SHADE_WAVES * 2 * 64 * SHADE_PREFETCH_REGS * 8; /* two record slots per wave */
+    ctx->shade_lds += (size_t)SHADE_WAVES * 2 * 64 * SHADE_PREFETCH_REGS * 8; /* two record slots per wave (the coefficient words of plastic vertices are read back from them) */
     int s_per_cu = 0;
     shade_sets(S, &ctx->shade_sets, &ctx->tail_first, &ctx->tail_count);
     switch (ctx->shade_sets)
