@@ -125,14 +125,6 @@ def roofline(dominant, kernel_ms, launches, paths_per_launch, model, workload, x
     `traffic` is the measured HBM bytes per launch from the same profile and `hbm_measured_frac` what that is of 8 TB/s.
     SURVEY 8d's byte model (a design that streams path state through HBM) is reported under `algorithmic_model`, as a model:
     this design does not move those bytes, so they are never divided by time into a bandwidth."""
-    avg_ms = {k: (kernel_ms[k] / launches if launches else 0.0) for k in kernel_ms}
-    out = {"bound": "fp64_valu", "kernel": "drt_%s_kernel" % dominant, "achieved": None, "peak": round(VALU_PEAK_GCYCLES, 1),
-           "unit": "G SIMD-cycles/s of vector issue", "frac": None,
-           "frac_is": "vector-issue occupancy: the share of SIMD cycles in which the kernel issues a vector instruction "
-                      "(SQ_ACTIVE_INST_VALU x 4 / cycles available) -- how busy the pipe is, NOT useful work / peak; "
-                      "useful f64 work against the peak is `fp64` beside it",
-           "traffic": None, "hbm_measured_frac": None,
-           "launch": {"paths": paths_per_launch, "avg_ms": round(avg_ms[dominant], 4), "count": launches}}
     prof = None
     ppath = os.path.join(REPO, "profiles", profile_name)
     stale = None
@@ -145,6 +137,25 @@ def roofline(dominant, kernel_ms, launches, paths_per_launch, model, workload, x
                     stale = "profiles/%s was taken from kernel sources %s, this build is %s" % (profile_name, pj.get("csrc_sha"), csrc_sha())
         except Exception:
             prof = None
+    kernel_ms = dict(kernel_ms)
+    if prof and "bounce" in prof["kernels"] and "primary" in prof["kernels"]:
+        # scenes behind the hierarchy: the library times the trace STAGE (drt_primary_kernel + drt_bounce_kernel) with one pair of HIP
+        # events; the stage's live time is split between the two kernels in the proportion of their traced durations
+        tb = prof["kernels"]["bounce"].get("avg_launch_ms_traced", 0.0) * prof["kernels"]["bounce"].get("launches_traced", 0)
+        tp_ = prof["kernels"]["primary"].get("avg_launch_ms_traced", 0.0) * prof["kernels"]["primary"].get("launches_traced", 0)
+        if tb + tp_ > 0:
+            kernel_ms["bounce"] = kernel_ms["trace"] * tb / (tb + tp_)
+            kernel_ms["primary"] = kernel_ms["trace"] * tp_ / (tb + tp_)
+            del kernel_ms["trace"]
+            dominant = max(kernel_ms, key=lambda k: kernel_ms[k])
+    avg_ms = {k: (kernel_ms[k] / launches if launches else 0.0) for k in kernel_ms}
+    out = {"bound": "fp64_valu", "kernel": "drt_%s_kernel" % dominant, "workload_key": workload, "achieved": None, "peak": round(VALU_PEAK_GCYCLES, 1),
+           "unit": "G SIMD-cycles/s of vector issue", "frac": None,
+           "frac_is": "vector-issue occupancy: the share of SIMD cycles in which the kernel issues a vector instruction "
+                      "(SQ_ACTIVE_INST_VALU x 4 / cycles available) -- how busy the pipe is, NOT useful work / peak; "
+                      "useful f64 work against the peak is `fp64` beside it",
+           "traffic": None, "hbm_measured_frac": None,
+           "launch": {"paths": paths_per_launch, "avg_ms": round(avg_ms[dominant], 4), "count": launches}}
     if prof:
         per_kernel = {}
         for k, e in prof["kernels"].items():
@@ -176,13 +187,13 @@ def roofline(dominant, kernel_ms, launches, paths_per_launch, model, workload, x
             # per-path counters of another build times this build's timings would be a number about neither
             out.update({"achieved": None, "frac": None, "stale_profile": stale})
     else:
-        out["note"] = "no committed PMC profile matches this workload (profiles/roofline.json): vector-issue and HBM fractions not reported"
+        out["note"] = "no committed PMC profile matches this workload (profiles/%s): vector-issue and HBM fractions not reported" % profile_name
     out["algorithmic_model"] = {
         "what": "SURVEY 8d byte model of a design that streams path state through HBM; a MODEL, not traffic -- this design keeps "
                 "throughput and radiance spectra in registers, so these bytes are not moved and are not a bandwidth",
         "bytes_per_path": {k: round(v, 1) for k, v in model.items()},
-        "bytes_per_launch": round(model[dominant] * paths_per_launch),
-        "measured_traffic_over_model": (round(out["traffic"] / (model[dominant] * paths_per_launch), 4) if out["traffic"] else None)}
+        "bytes_per_launch": round(model.get(dominant, model["trace"]) * paths_per_launch),
+        "measured_traffic_over_model": (round(out["traffic"] / (model.get(dominant, model["trace"]) * paths_per_launch), 4) if out["traffic"] else None)}
     return out
 
 
@@ -421,7 +432,7 @@ def main():
         for r in live:
             r.synchronize()
         sts = [r.stats() for r in live]
-        out = {k: sum(getattr(st, k) for st in sts) for k in ("paths", "trace_ms", "shade_ms", "closest_hit_scans", "shaded_vertices", "redone_launches")}
+        out = {k: sum(getattr(st, k) for st in sts) for k in ("paths", "trace_ms", "shade_ms", "closest_hit_scans", "shaded_vertices", "redone_launches", "launches")}
         out["pool_bytes"] = sum(st.record_pool_blocks * st.record_block_bytes for st in sts)
         out["pool_peak_bytes"] = max(st.record_pool_peak * st.record_block_bytes for st in sts)
         return out
@@ -484,9 +495,11 @@ def main():
         model = algorithmic_bytes(S, v_int, v_shade, xyz)
         dominant = "shade" if shade_ms >= trace_ms else "trace"
         # per launch: paths per kernel launch and its average duration (launches = batches)
-        paths_per_launch = batch_spp * block_pixels
+        # kernel pairs the library launched in the timed region (drt_stats.launches) and the paths of an average one: a long call on a
+        # large frame goes out in row blocks whose pairs take other sample counts than batch_spp x the block's pixels
+        launches = max(1, int(st1["launches"] - st0["launches"]))
+        paths_per_launch = max(1, int(round(paths_rank / launches)))
         paths_per_launch_all = batch_spp * sum(fb.rows for fb in blocks) * W  # this rank's launches side by side (one context per row block)
-        launches = max(1, round(paths_rank / max(paths_per_launch, 1)))
         kernel_ms = {"trace": trace_ms, "shade": shade_ms}
         scene_stem = wl_scene.replace(".scn", "").replace("@", "").replace(":", "_")
         roof = roofline(dominant, kernel_ms, launches, paths_per_launch, model,

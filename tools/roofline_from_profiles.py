@@ -50,7 +50,9 @@ def read_trace(root):
     for f in find(root, "*kernel_stats.csv"):
         for row in csv.DictReader(open(f)):
             k = kernel_of(row.get("Name", ""))
-            if k:
+            # two instantiations of one kernel may show up (drt_create's sizing launch is one call of a fraction of a millisecond): the
+            # one the time goes to is the one the workload runs
+            if k and (k not in out or float(row["TotalDurationNs"]) > out[k]["total_ns"]):
                 out[k] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]), "total_ns": float(row["TotalDurationNs"]),
                           "name": row["Name"].split("(")[0]}
     return out
@@ -81,11 +83,19 @@ def read_counters(root):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("root")
-    ap.add_argument("--paths-per-launch", type=int, required=True)
-    ap.add_argument("--workload", required=True)
+    ap.add_argument("--paths-per-launch", type=int, default=0)
+    ap.add_argument("--workload", default="")
+    ap.add_argument("--bench-log", default="", help="a log holding bench.py's JSON line of the profiled command: paths per launch and workload key are taken from it")
     ap.add_argument("--source", default="")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
+    if a.bench_log:
+        line = [l for l in open(a.bench_log) if l.startswith("{")][-1]
+        roof = json.loads(line)["roofline"]
+        a.paths_per_launch = a.paths_per_launch or int(roof["launch"]["paths"])
+        a.workload = a.workload or roof["workload_key"]
+    if not a.paths_per_launch or not a.workload:
+        sys.exit("give --bench-log, or --paths-per-launch and --workload")
     trace = read_trace(a.root)
     agg, disp, span, regs = read_counters(a.root)
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
