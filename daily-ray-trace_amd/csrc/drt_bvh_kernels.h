@@ -91,7 +91,10 @@ __device__ __forceinline__ uint64_t path_key(const TraceParams &tp, const PathSt
 
 #define PRIMARY_BLOCK 256
 
-__global__ __launch_bounds__(PRIMARY_BLOCK) void drt_primary_kernel(DevScene sc, DevCamera cam, TraceParams tp, uint64_t *__restrict__ headers,
+#ifndef DRT_PRIMARY_WAVES_PER_SIMD
+#define DRT_PRIMARY_WAVES_PER_SIMD 6 /* 80 registers, 28 bytes of scratch: config 5 trace stage 506 -> 500 ms (5 and 8 waves: 501, 500) */
+#endif
+__global__ __launch_bounds__(PRIMARY_BLOCK, DRT_PRIMARY_WAVES_PER_SIMD) void drt_primary_kernel(DevScene sc, DevCamera cam, TraceParams tp, uint64_t *__restrict__ headers,
                                                                     int32_t *__restrict__ hits, unsigned long long *__restrict__ counters,
                                                                     PrimaryHit *__restrict__ primary, uint64_t *__restrict__ queue,
                                                                     unsigned long long *__restrict__ queue_count)
