@@ -935,7 +935,11 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
         /* a context kept across many frames: 64 M paths per kernel pair keep the launches' last rounds short (work
          * queues) -- but never fewer than 16 samples per pixel and launch where memory allows, because the film is read and written
          * once per launch: 3328 bytes per pixel, which at 4 samples a launch (the 4096^2 frame of config 5) was a third of the frame */
-        const uint64_t by_paths = std::max<uint64_t>(1, std::min<uint64_t>(DRT_DEFAULT_MAX_BATCH, (64ull << 20) / npx));
+        /* (256 M paths where memory allows: 288 GB of HBM hold the 116 GB of records that takes on the Cornell frame, and each launch
+         * ends on a partly idle chip: 1024^2 x 256 spp in one pair instead of four, 1525 -> 1568 Mpaths/s; the loop below halves the
+         * launch until its records fit half of what is free) */
+        const uint64_t resident_paths = getenv("DRT_RESIDENT_PATHS_M") ? (uint64_t)std::max(1, atoi(getenv("DRT_RESIDENT_PATHS_M"))) << 20 : (256ull << 20);
+        const uint64_t by_paths = std::max<uint64_t>(1, std::min<uint64_t>(DRT_DEFAULT_MAX_BATCH, resident_paths / npx));
         batch = (uint32_t)std::max<uint64_t>(by_paths, 16);
         if (params->spp) batch = std::min(batch, params->spp);
     }
