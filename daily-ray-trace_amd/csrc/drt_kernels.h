@@ -1103,7 +1103,7 @@ struct ShadeParams
     uint32_t n_samples, first_sample, vertex_words, block_words; /* a vertex record and a pool block (four vertices) in 8-byte words */
     uint32_t n_lights, batch;
     const uint32_t *overflow; /* the trace launch ran out of record blocks: nothing here is touched */
-    uint32_t vertex_shift, pad3; /* log2(vertex_words) */
+    uint32_t vertex_shift, mode; /* log2(vertex_words); DIAGNOSTIC mode: 1 main pass only, 2 tail pass only (timing probes; the film is then incomplete) */
     uint32_t tail_first, tail_count; /* wavelengths [tail_first, tail_first + tail_count) go through the packed tail pass (0: none) */
     uint32_t chunk, sub_pixels;      /* pixels per group (= tail packing size when there is a tail); pixels per main-pass work item */
     uint32_t light0_em_spd, tail_staged;  /* emission SPD row of light 0 (what every light block of light 0 says); tail_staged: the trace
@@ -1227,6 +1227,11 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
                                   waves at any depth (the kernel is bound by what it issues); one ahead is the fewest
                                   register moves and LDS writes: 106.0 ms against 106.8 with two */
 #define SHADE_PIXEL_CHUNK 16 /* pixels per group when there is no tail pass (with one: 64 / tail wavelengths) */
+/* A wave's own LDS region behind the SPD table: the main pass keeps two record slots there (2 x 64 x SHADE_PREFETCH_REGS words); the
+ * tail pass, which a wave runs at other times, the headers of a window of samples of its group's pixels (TAIL_WINDOW_WORDS). */
+#define TAIL_WINDOW_ENTRIES 112u /* headers of a window: three words each (words 0, 1, 2), and a 16-bit task list entry */
+#define TAIL_WINDOW_WORDS (3u * TAIL_WINDOW_ENTRIES + TAIL_WINDOW_ENTRIES / 4u) /* 2.9 KB */
+#define SHADE_WAVE_LDS_WORDS ((2u * 64u * SHADE_PREFETCH_REGS) > TAIL_WINDOW_WORDS ? (2u * 64u * SHADE_PREFETCH_REGS) : TAIL_WINDOW_WORDS)
 
 #define XYZ_FILM_WORDS 8 /* XYZ film mode, per pixel: X, Y, Z numerators of the main pass, filter sum, X, Y, Z of the tail pass, unused */
 
@@ -1238,7 +1243,7 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
  * (as a kernel of its own, at 4 to 8 waves per SIMD, it was 12-27 ms slower: measured).
  */
 template <bool SPDS_IN_LDS, bool XYZ>
-__device__ __forceinline__ void shade_tail_group(const DevScene &sc, const ShadeParams &sp, const double *lds, const uint64_t *__restrict__ records,
+__device__ __forceinline__ void shade_tail_group(const DevScene &sc, const ShadeParams &sp, const double *lds, uint64_t *wave_lds, const uint64_t *__restrict__ records,
                                                  const uint64_t *__restrict__ headers, double *__restrict__ film_pixels,
                                                  double *__restrict__ film_avgs, double *__restrict__ film_vars, uint64_t chunk_base,
                                                  uint64_t chunk_end, uint32_t lane)
@@ -1261,148 +1266,225 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
      * tail_stage). The wave runs for the pixel with the most vertices in the batch, and the general code only runs
      * when it is what most lanes need.
      */
-    uint32_t s = act ? 0u : sp.n_samples; /* lanes without a pixel are done from the start */
+    /*
+     * Phase A -- radiance. The work is a list of PATHS, dealt to whichever lane group is free.
+     * A window of samples of the group's pixels is taken at a time (TAIL_WINDOW_ENTRIES headers: nine samples of twelve pixels at five
+     * tail wavelengths). The whole wave fetches the window's headers in coalesced loads; a lane that finds its header without a vertex
+     * -- three in five -- closes that sample at once (emission of what the path ended on, vignette: :452-457, :615, a few LDS reads and
+     * stores), the others are entered in a task list in LDS (ballot + prefix count) with their header words beside it. Then every
+     * group of R lanes -- one lane per tail wavelength -- takes the next task from the list whenever it is free, replays that path
+     * vertex by vertex with its own cursor, parks the result in tail_stage and takes the next. (Before: a group walked ITS pixel's samples
+     * in order, a memory round trip for every header -- the empty ones too -- and the wave ran as long as its pixel with the most
+     * vertices: 220 iterations for twelve pixels' 64 samples where the vertices alone are 106 a group.) The header says which of a
+     * path's first 16 vertices are plastic (bits 48-63), so an iteration is EITHER a plastic step or a general step -- whichever more
+     * lanes are waiting for.
+     */
+    const uint32_t n_groups = 64u / R;                 /* lane groups = the pixels of a full chunk */
+    const uint32_t win = TAIL_WINDOW_ENTRIES / n_groups; /* samples per window */
+    uint16_t *task_list = (uint16_t *)(wave_lds + 3u * TAIL_WINDOW_ENTRIES);
+    const uint32_t leader = g * R;                     /* the group's first lane */
+    const bool in_group = g < n_groups;
     uint32_t v = 0, n_shaded = 0;
     uint64_t ph0 = 0; /* the header's first word: vertex count, how the path ended, flags (fields taken out where they are used) */
     double vignette = 0.0, throughput = 1.0, dst = 0.0;
-    uint64_t ph2 = 0, ph3 = 0; /* the path's block words */
+    uint64_t ph2 = 0; /* the path's first two block words */
+    uint64_t slot = 0; /* the path's header / staging slot: pixel * batch + sample */
     const uint64_t *vcur = records; /* the record of vertex v */
     const bool one_light = sp.n_lights == 1u;
     const double em0 = spd_at(table, S, one_light ? sp.light0_em_spd : 0u, lam); /* light 0's emission at this lane's wavelength */
-    auto open_sample = [&]() {
-        const uint64_t slot = pix_l * sp.batch + s;
-        const uint64_t h0 = headers[slot * REC_HEADER_WORDS], h1 = headers[slot * REC_HEADER_WORDS + 1];
-        ph2 = headers[slot * REC_HEADER_WORDS + 2];
-        ph3 = headers[slot * REC_HEADER_WORDS + 3];
-        ph0 = h0;
-        n_shaded = (uint32_t)(h0 & 0xFFFFu);
-        vignette = word_as_double(h1);
-        v = 0;
-        vcur = records + (uint64_t)(uint32_t)ph2 * sp.block_words; /* vertex 0 opens the header's first block */
-        throughput = 1.0;
-        dst = 0.0;
-    };
-    if (sp.tail_staged) s = sp.n_samples; /* nothing to replay: drt_trace_kernel<true, true> staged every sample */
-    if (s < sp.n_samples) open_sample();
-    while (__any(s < sp.n_samples))
+    /* header word 3 (the blocks of vertices 8 and up) is fetched when a path gets that far */
+    auto deep_blocks = [&](uint32_t vertex) -> uint64_t { return vertex >= 2u * REC_BLOCK_VERTICES ? headers[slot * REC_HEADER_WORDS + 3] : 0ull; };
+    for (uint32_t s0 = sp.tail_staged ? sp.n_samples : 0u; s0 < sp.n_samples; s0 += win) /* tail_staged: nothing to replay, drt_trace_kernel<true, true> staged every sample */
     {
-        const bool has_vertex = s < sp.n_samples && v < n_shaded;
-        const bool is_plastic = has_vertex && v < 16u && (((uint32_t)(ph0 >> 48) >> v) & 1u); /* bits 48-63: two-lobe plastic */
-        const bool is_general = has_vertex && !is_plastic;
-        const uint32_t n_plastic = (uint32_t)__popcll(__ballot(is_plastic)), n_general = (uint32_t)__popcll(__ballot(is_general));
-        if (n_plastic > 0 && n_plastic >= n_general)
+        const uint32_t s_end = s0 + win < sp.n_samples ? s0 + win : sp.n_samples;
+        const uint32_t n_win = s_end - s0, n_px = (uint32_t)(chunk_end - chunk_base);
+        uint32_t n_tasks = 0; /* wave-uniform */
+        for (uint32_t e0 = 0; e0 < n_px * n_win; e0 += 64u)
         {
-            if (is_plastic)
+            const uint32_t e = e0 + lane;
+            const bool valid = e < n_px * n_win;
+            const uint32_t ge = valid ? e / n_win : 0u, off = valid ? e - ge * n_win : 0u;
+            const uint64_t eslot = (chunk_base + ge) * (uint64_t)sp.batch + s0 + off;
+            uint64_t h0 = 0, h1 = 0, h2 = 0;
+            if (valid)
             {
-                /* bdsf() over {bp_diffuse_bdsf, bp_glossy_bdsf}, straight-line (as in the main pass) */
-                const uint64_t *vrec = vcur;
-                const uint64_t w1 = vrec[1];
-                const double dir_pdf = word_as_double(vrec[4]);
-                const double s_a_in = word_as_double(vrec[5]), s_spec = word_as_double(vrec[6]);
-                const uint32_t i_diffuse = (uint32_t)(w1 >> 16) & 0xFFFFu, i_glossy = (uint32_t)(w1 >> 32) & 0xFFFFu;
-                const double diffuse_pi = spd_at(table, S, i_diffuse, lam), glossy = spd_at(table, S, i_glossy, lam);
-                double contribution = 0.0;
-                if (one_light && v < 8u)
+                const uint64_t *h = headers + eslot * REC_HEADER_WORDS;
+                h0 = h[0];
+                h1 = h[1];
+                h2 = h[2];
+            }
+            const bool has_path = valid && (h0 & 0xFFFFu) != 0u;
+            if (valid && !has_path)
+            {
+                /* no vertex: the sample is what the path ended on, with throughput 1 and nothing gathered (:452-457, :615) */
+                const bool emissive = ((uint32_t)(h0 >> 16) & HDR_TERM_MASK) == 1u;
+                const uint32_t row = (uint32_t)(h0 >> 32) & 0xFFFFu;
+                for (uint32_t t = 0; t < R; t += 1)
                 {
-                    /* one light, and the header says whether it is visible: its three numbers fetched together with the vertex's own
-                     * words (no round trip for a flag word first), its emission row known in advance */
-                    if (((uint32_t)(ph0 >> 24) >> v) & 1u) /* bits 24-31: light 0 visible */
+                    double d = 0.0;
+                    if (emissive) d = d + 1.0 * spd_at(table, S, row, sp.tail_first + t);
+                    sp.tail_stage[eslot * R + t] = d * word_as_double(h1);
+                }
+            }
+            const unsigned long long m = __ballot(has_path);
+            if (has_path)
+            {
+                const uint32_t k = n_tasks + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                task_list[k] = (uint16_t)e;
+                uint64_t *w = wave_lds + e * 3u;
+                w[0] = h0;
+                w[1] = h1;
+                w[2] = h2;
+            }
+            n_tasks += (uint32_t)__popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier(); /* the other lanes' LDS writes are in order before this lane's reads (one wave, in-order LDS) */
+        uint32_t next_task = 0; /* wave-uniform */
+        bool busy = false;      /* the group is on a path */
+        for (;;)
+        {
+            /* groups without a path take the next ones off the list, in lane order */
+            const unsigned long long want = __ballot(!busy && in_group && lane == leader);
+            if (want != 0ull)
+            {
+                const uint32_t mine = next_task + (uint32_t)__popcll(want & ((1ull << leader) - 1ull));
+                if (!busy && in_group && mine < n_tasks)
+                {
+                    const uint32_t e = task_list[mine];
+                    const uint64_t *w = wave_lds + e * 3u;
+                    const uint32_t ge = e / n_win, off = e - ge * n_win;
+                    slot = (chunk_base + ge) * (uint64_t)sp.batch + s0 + off;
+                    ph0 = w[0];
+                    vignette = word_as_double(w[1]);
+                    ph2 = w[2];
+                    n_shaded = (uint32_t)(ph0 & 0xFFFFu);
+                    v = 0;
+                    vcur = records + (uint64_t)(uint32_t)ph2 * sp.block_words; /* vertex 0 opens the header's first block */
+                    throughput = 1.0;
+                    dst = 0.0;
+                    busy = true;
+                }
+                next_task += (uint32_t)__popcll(want);
+            }
+            if (!__any(busy)) break;
+            const bool has_vertex = busy && v < n_shaded;
+            const bool is_plastic = has_vertex && v < 16u && (((uint32_t)(ph0 >> 48) >> v) & 1u); /* bits 48-63: two-lobe plastic */
+            const bool is_general = has_vertex && !is_plastic;
+            const uint32_t n_plastic = (uint32_t)__popcll(__ballot(is_plastic)), n_general = (uint32_t)__popcll(__ballot(is_general));
+            if (n_plastic > 0 && n_plastic >= n_general)
+            {
+                if (is_plastic)
+                {
+                    /* bdsf() over {bp_diffuse_bdsf, bp_glossy_bdsf}, straight-line (as in the main pass) */
+                    const uint64_t *vrec = vcur;
+                    const uint64_t w1 = vrec[1];
+                    const double dir_pdf = word_as_double(vrec[4]);
+                    const double s_a_in = word_as_double(vrec[5]), s_spec = word_as_double(vrec[6]);
+                    const uint32_t i_diffuse = (uint32_t)(w1 >> 16) & 0xFFFFu, i_glossy = (uint32_t)(w1 >> 32) & 0xFFFFu;
+                    const double diffuse_pi = spd_at(table, S, i_diffuse, lam), glossy = spd_at(table, S, i_glossy, lam);
+                    double contribution = 0.0;
+                    if (one_light && v < 8u)
                     {
+                        /* one light, and the header says whether it is visible: its three numbers fetched together with the vertex's own
+                         * words (no round trip for a flag word first), its emission row known in advance */
+                        if (((uint32_t)(ph0 >> 24) >> v) & 1u) /* bits 24-31: light 0 visible */
+                        {
+                            const uint64_t *lrec = vrec + REC_VERTEX_WORDS;
+                            const double c = word_as_double(lrec[1]), a_in = word_as_double(lrec[2]), spec = word_as_double(lrec[3]);
+                            double reflectance = diffuse_pi * a_in + 0.0;
+                            reflectance = (glossy * spec) * a_in + reflectance;
+                            contribution = contribution + reflectance;
+                            contribution = contribution * em0;
+                            contribution = contribution * c;
+                        }
+                    }
+                    else if (one_light)
+                    {
+                        /* later vertices: the flag word says whether the light is visible; it travels WITH the light's three numbers and
+                         * the vertex's own words, and the result is computed either way and then chosen -- behind a branch the loads
+                         * would wait for the flag word's round trip first */
                         const uint64_t *lrec = vrec + REC_VERTEX_WORDS;
+                        const uint64_t lw0 = lrec[0];
+                        const double c = word_as_double(lrec[1]), a_in = word_as_double(lrec[2]), spec = word_as_double(lrec[3]);
+                        double reflectance = diffuse_pi * a_in + 0.0;
+                        reflectance = (glossy * spec) * a_in + reflectance;
+                        double lit = 0.0 + reflectance;
+                        lit = lit * em0;
+                        lit = lit * c;
+                        contribution = ((uint32_t)(lw0 >> 16) & FLAG_VISIBLE) ? lit : 0.0;
+                    }
+                    else
+                    for (uint32_t l = 0; l < sp.n_lights; l += 1)
+                    {
+                        const uint64_t *lrec = vrec + REC_VERTEX_WORDS + l * REC_LIGHT_WORDS;
+                        const uint64_t lw0 = lrec[0];
+                        if (!((uint32_t)(lw0 >> 16) & FLAG_VISIBLE)) continue;
                         const double c = word_as_double(lrec[1]), a_in = word_as_double(lrec[2]), spec = word_as_double(lrec[3]);
                         double reflectance = diffuse_pi * a_in + 0.0;
                         reflectance = (glossy * spec) * a_in + reflectance;
                         contribution = contribution + reflectance;
-                        contribution = contribution * em0;
+                        contribution = contribution * spd_at(table, S, (uint32_t)(lw0 & 0xFFFFu), lam);
                         contribution = contribution * c;
                     }
+                    dst = dst + throughput * contribution;
+                    double reflectance = diffuse_pi * s_a_in + 0.0;
+                    reflectance = (glossy * s_spec) * s_a_in + reflectance;
+                    reflectance = reflectance * dir_pdf;
+                    throughput = throughput * reflectance;
+                    v += 1;
+                    if (v < n_shaded) vcur = (v & (REC_BLOCK_VERTICES - 1u)) != 0u ? vcur + vw : path_vertex(records, sp.block_words, vw, ph2, deep_blocks(v), v); /* the next record: the one behind, or a new block */
                 }
-                else if (one_light)
-                {
-                    /* later vertices: the flag word says whether the light is visible; it travels WITH the light's three numbers and
-                     * the vertex's own words, and the result is computed either way and then chosen -- behind a branch the loads
-                     * would wait for the flag word's round trip first */
-                    const uint64_t *lrec = vrec + REC_VERTEX_WORDS;
-                    const uint64_t lw0 = lrec[0];
-                    const double c = word_as_double(lrec[1]), a_in = word_as_double(lrec[2]), spec = word_as_double(lrec[3]);
-                    double reflectance = diffuse_pi * a_in + 0.0;
-                    reflectance = (glossy * spec) * a_in + reflectance;
-                    double lit = 0.0 + reflectance;
-                    lit = lit * em0;
-                    lit = lit * c;
-                    contribution = ((uint32_t)(lw0 >> 16) & FLAG_VISIBLE) ? lit : 0.0;
-                }
-                else
-                for (uint32_t l = 0; l < sp.n_lights; l += 1)
-                {
-                    const uint64_t *lrec = vrec + REC_VERTEX_WORDS + l * REC_LIGHT_WORDS;
-                    const uint64_t lw0 = lrec[0];
-                    if (!((uint32_t)(lw0 >> 16) & FLAG_VISIBLE)) continue;
-                    const double c = word_as_double(lrec[1]), a_in = word_as_double(lrec[2]), spec = word_as_double(lrec[3]);
-                    double reflectance = diffuse_pi * a_in + 0.0;
-                    reflectance = (glossy * spec) * a_in + reflectance;
-                    contribution = contribution + reflectance;
-                    contribution = contribution * spd_at(table, S, (uint32_t)(lw0 & 0xFFFFu), lam);
-                    contribution = contribution * c;
-                }
-                dst = dst + throughput * contribution;
-                double reflectance = diffuse_pi * s_a_in + 0.0;
-                reflectance = (glossy * s_spec) * s_a_in + reflectance;
-                reflectance = reflectance * dir_pdf;
-                throughput = throughput * reflectance;
-                v += 1;
-                if (v < n_shaded) vcur = (v & (REC_BLOCK_VERTICES - 1u)) != 0u ? vcur + vw : path_vertex(records, sp.block_words, vw, ph2, ph3, v); /* the next record: the one behind, or a new block */
             }
-        }
-        else if (n_general > 0)
-        {
-            if (is_general)
+            else if (n_general > 0)
             {
-                /* any BDSF list (also plastic vertices beyond the header's 16 flags) */
-                const uint64_t *vrec = vcur;
-                const uint64_t list = vrec[0], w1 = vrec[1], w2 = vrec[2];
-                const double on_dot = word_as_double(vrec[3]), dir_pdf = word_as_double(vrec[4]);
-                const double s_a_in = word_as_double(vrec[5]), s_spec = word_as_double(vrec[6]);
-                const uint32_t num_bdsfs = (uint32_t)(w1 & 0xFFu);
-                const uint32_t sflags = (uint32_t)(w1 >> 8) & 0xFFu;
-                const uint32_t i_diffuse = (uint32_t)(w1 >> 16) & 0xFFFFu, i_glossy = (uint32_t)(w1 >> 32) & 0xFFFFu;
-                const double diffuse_pi = spd_at(table, S, i_diffuse, lam), glossy = spd_at(table, S, i_glossy, lam);
-                const double mirror = spd_at(table, S, (uint32_t)(w1 >> 48) & 0xFFFFu, lam);
-                uint32_t f0, f1, f2;
-                bool paired;
-                fresnel_rows(w2, f0, f1, f2, paired);
-                const double ir = spd_at(table, S, f0, lam), tr = spd_at(table, S, f1, lam), te = spd_at(table, S, f2, lam);
-                double contribution = 0.0;
-                for (uint32_t l = 0; l < sp.n_lights; l += 1)
+                if (is_general)
                 {
-                    const uint64_t *lrec = vrec + REC_VERTEX_WORDS + l * REC_LIGHT_WORDS;
-                    const uint64_t lw0 = lrec[0];
-                    const uint32_t lflags = (uint32_t)(lw0 >> 16) & 0xFFu;
-                    if (!(lflags & FLAG_VISIBLE)) continue;
-                    double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse_pi, glossy, mirror, ir, tr, te, on_dot,
-                                                            word_as_double(lrec[2]), word_as_double(lrec[3]), word_as_double(lrec[4]),
-                                                            word_as_double(lrec[5]), lflags, paired);
-                    contribution = contribution + reflectance;
-                    contribution = contribution * spd_at(table, S, (uint32_t)(lw0 & 0xFFFFu), lam);
-                    contribution = contribution * word_as_double(lrec[1]);
+                    /* any BDSF list (also plastic vertices beyond the header's 16 flags) */
+                    const uint64_t *vrec = vcur;
+                    const uint64_t list = vrec[0], w1 = vrec[1], w2 = vrec[2];
+                    const double on_dot = word_as_double(vrec[3]), dir_pdf = word_as_double(vrec[4]);
+                    const double s_a_in = word_as_double(vrec[5]), s_spec = word_as_double(vrec[6]);
+                    const uint32_t num_bdsfs = (uint32_t)(w1 & 0xFFu);
+                    const uint32_t sflags = (uint32_t)(w1 >> 8) & 0xFFu;
+                    const uint32_t i_diffuse = (uint32_t)(w1 >> 16) & 0xFFFFu, i_glossy = (uint32_t)(w1 >> 32) & 0xFFFFu;
+                    const double diffuse_pi = spd_at(table, S, i_diffuse, lam), glossy = spd_at(table, S, i_glossy, lam);
+                    const double mirror = spd_at(table, S, (uint32_t)(w1 >> 48) & 0xFFFFu, lam);
+                    uint32_t f0, f1, f2;
+                    bool paired;
+                    fresnel_rows(w2, f0, f1, f2, paired);
+                    const double ir = spd_at(table, S, f0, lam), tr = spd_at(table, S, f1, lam), te = spd_at(table, S, f2, lam);
+                    double contribution = 0.0;
+                    for (uint32_t l = 0; l < sp.n_lights; l += 1)
+                    {
+                        const uint64_t *lrec = vrec + REC_VERTEX_WORDS + l * REC_LIGHT_WORDS;
+                        const uint64_t lw0 = lrec[0];
+                        const uint32_t lflags = (uint32_t)(lw0 >> 16) & 0xFFu;
+                        if (!(lflags & FLAG_VISIBLE)) continue;
+                        double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse_pi, glossy, mirror, ir, tr, te, on_dot,
+                                                                word_as_double(lrec[2]), word_as_double(lrec[3]), word_as_double(lrec[4]),
+                                                                word_as_double(lrec[5]), lflags, paired);
+                        contribution = contribution + reflectance;
+                        contribution = contribution * spd_at(table, S, (uint32_t)(lw0 & 0xFFFFu), lam);
+                        contribution = contribution * word_as_double(lrec[1]);
+                    }
+                    dst = dst + throughput * contribution;
+                    double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse_pi, glossy, mirror, ir, tr, te, on_dot, s_a_in, s_spec,
+                                                            word_as_double(vrec[7]), word_as_double(vrec[8]), sflags, paired);
+                    reflectance = reflectance * dir_pdf;
+                    throughput = throughput * reflectance;
+                    v += 1;
+                    if (v < n_shaded) vcur = (v & (REC_BLOCK_VERTICES - 1u)) != 0u ? vcur + vw : path_vertex(records, sp.block_words, vw, ph2, deep_blocks(v), v); /* the next record: the one behind, or a new block */
                 }
-                dst = dst + throughput * contribution;
-                double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse_pi, glossy, mirror, ir, tr, te, on_dot, s_a_in, s_spec,
-                                                        word_as_double(vrec[7]), word_as_double(vrec[8]), sflags, paired);
-                reflectance = reflectance * dir_pdf;
-                throughput = throughput * reflectance;
-                v += 1;
-                if (v < n_shaded) vcur = (v & (REC_BLOCK_VERTICES - 1u)) != 0u ? vcur + vw : path_vertex(records, sp.block_words, vw, ph2, ph3, v); /* the next record: the one behind, or a new block */
+            }
+            if (busy && v >= n_shaded)
+            {
+                /* the path's last vertex is done: close the sample, :452-457 and :615 */
+                if (((uint32_t)(ph0 >> 16) & HDR_TERM_MASK) == 1u) dst = dst + throughput * spd_at(table, S, (uint32_t)(ph0 >> 32) & 0xFFFFu, lam);
+                sp.tail_stage[slot * R + j] = dst * vignette;
+                busy = false;
             }
         }
-        if (s < sp.n_samples && v >= n_shaded)
-        {
-            /* the path's last vertex is done (or it had none): close the sample, :452-457 and :615 */
-            if (((uint32_t)(ph0 >> 16) & HDR_TERM_MASK) == 1u) dst = dst + throughput * spd_at(table, S, (uint32_t)(ph0 >> 32) & 0xFFFFu, lam);
-            sp.tail_stage[((chunk_base + g) * (uint64_t)sp.batch + s) * R + j] = dst * vignette; /* the address from scratch: a pointer kept live costs two registers */
-            s += 1;
-            if (s < sp.n_samples) open_sample();
-        }
+        __builtin_amdgcn_wave_barrier(); /* every lane is through the window before its headers are overwritten */
     }
     double *px = film_pixels + pix_l * (uint64_t)(XYZ ? XYZ_FILM_WORDS : S + 1);
     double *pa = XYZ ? nullptr : film_avgs + pix_l * (uint64_t)S;
@@ -1476,7 +1558,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
     }
     const uint32_t lane = threadIdx.x & 63u;
     /* behind the SPD table: two record slots per wave (see the sample loop) */
-    uint64_t *rec_lds = (uint64_t *)(lds + (SPDS_IN_LDS ? (size_t)sc.n_spd * S : 0)) + (size_t)(threadIdx.x >> 6) * (2u * 64u * SHADE_PREFETCH_REGS);
+    uint64_t *rec_lds = (uint64_t *)(lds + (SPDS_IN_LDS ? (size_t)sc.n_spd * S : 0)) + (size_t)(threadIdx.x >> 6) * SHADE_WAVE_LDS_WORDS;
     const uint32_t vw = sp.vertex_words;                 /* power of two >= 16 */
     const uint32_t vpr = vw <= 64 ? 64u / vw : 0u;       /* vertices per 64-word register (0: records wider than a register) */
     const uint32_t n_fast_regs = vpr * SHADE_PREFETCH_REGS;
@@ -1542,6 +1624,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
             if (tail_item || main_base > chunk_end) main_base = main_end = chunk_end; /* nothing for the main pass */
         }
 
+      if (sp.mode == 2u) main_base = main_end;
       for (uint64_t pix = main_base; pix < main_end; pix += 1)
       {
 
@@ -1967,7 +2050,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
         }
       }
 
-        if (tail_item) shade_tail_group<SPDS_IN_LDS, XYZ>(sc, sp, (const double *)lds, records, headers, film_pixels, film_avgs, film_vars, chunk_base, chunk_end, lane);
+        if (tail_item && sp.mode != 1u) shade_tail_group<SPDS_IN_LDS, XYZ>(sc, sp, (const double *)lds, rec_lds, records, headers, film_pixels, film_avgs, film_vars, chunk_base, chunk_end, lane);
     }
 }
 

@@ -838,7 +838,8 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     }
     /* shade kernel LDS: SPD tables + two record buffers per wave */
     ctx->shade_lds = ctx->spds_in_lds ? (size_t)ctx->dsc.n_spd * S * 8 : 0;
-    ctx->shade_lds += (size_t)SHADE_WAVES * 2 * 64 * SHADE_PREFETCH_REGS * 8; /* two record slots per wave (the coefficient words of plastic vertices are read back from them) */
+    ctx->shade_lds += (size_t)SHADE_WAVES * SHADE_WAVE_LDS_WORDS * 8; /* a wave's own region: two record slots in the main pass (the coefficient words of plastic
+                                                                          vertices are read back from them), a window of headers in the tail pass */
     int s_per_cu = 0;
     shade_sets(S, &ctx->shade_sets, &ctx->tail_first, &ctx->tail_count);
     switch (ctx->shade_sets)
@@ -1195,6 +1196,8 @@ static int enqueue_pair(drt_context *ctx, uint32_t first_sample, uint32_t n, uin
     sp.tail_stage = ctx->d_tail_stage;
     sp.light0_em_spd = ctx->light0_em_spd;
     sp.tail_staged = (ctx->trace_tail && ctx->d_tail_stage) ? 1u : 0u;
+    if (const char *e = getenv("DRT_DEBUG_SHADE_MODE")) sp.mode = (uint32_t)atoi(e); /* timing probe: 1 main pass only, 2 tail pass only */
+    if (const char *e = getenv("DRT_DEBUG_TAIL_PHASE_A_OFF")) sp.tail_staged = (uint32_t)atoi(e) ? 1u : sp.tail_staged;
     sp.cmf_rw = ctx->cmf_rw; sp.cmf_x = ctx->cmf_x; sp.cmf_y = ctx->cmf_y; sp.cmf_z = ctx->cmf_z;
     sp.chunk = ctx->tail_count ? 64u / ctx->tail_count : SHADE_PIXEL_CHUNK;
     uint64_t groups = (n_pix + sp.chunk - 1) / sp.chunk;

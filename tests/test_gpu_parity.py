@@ -297,6 +297,13 @@ def test_long_batches_and_work_queue_shapes_do_not_change_a_bit(monkeypatch):
         other = hip_render(bundle, params, batch=batch)
         for a, b in zip(base[:5], other[:5]):
             assert np.array_equal(a, b), "batch %d" % batch
+    # 256 samples of a pixel in one kernel pair (what a resident context takes on the 1024^2 frame: four windows of 64), and 300 in two
+    p300 = pydrt.make_params(16, 16, spp=300, max_depth=8, seed=3)
+    ref300 = hip_render(bundle, p300, batch=32)
+    for batch in (256, pydrt.BATCH_RESIDENT):
+        other = hip_render(bundle, p300, batch=batch)
+        for a, b in zip(ref300[:5], other[:5]):
+            assert np.array_equal(a, b), "batch %d of 300" % batch
     for subs, period in ((0, 0), (1, 0), (3, 1), (5, 2), (12, 0), (12, 12)):
         monkeypatch.setenv("DRT_SHADE_SUBS", str(subs))
         monkeypatch.setenv("DRT_TAIL_PERIOD", str(period))
