@@ -688,6 +688,7 @@ __device__ __forceinline__ void camera_ray(const DevCamera &cam, uint32_t scheme
 /* The trace kernel                                                                                */
 
 #define TRACE_BLOCK 256
+#define DRT_TRACE_TAIL_MAX 8u /* tail wavelengths the trace kernel carries at most (the launcher's rule: S mod 64 <= 8) */
 #ifndef DRT_TRACE_WAVES_PER_SIMD
 #define DRT_TRACE_WAVES_PER_SIMD 3 /* register budget: launch_bounds' 2nd argument is waves per SIMD */
 #endif
@@ -983,8 +984,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
                         const double *row_d = l_spd_tail + ((uint32_t)mat.diffuse_spd & 0xFFFFu) * TR;
                         const double *row_g = l_spd_tail + ((uint32_t)mat.glossy_spd & 0xFFFFu) * TR;
                         const double *row_e = l_spd_tail + t_em * TR;
-                        for (uint32_t j = 0; j < TR; j += 1)
+                        /* (a constant trip count, so that the compiler unrolls: the wavelengths' chains of dependent f64 operations then
+                         *  run side by side instead of one after the other) */
+#pragma unroll
+                        for (uint32_t j = 0; j < DRT_TRACE_TAIL_MAX; j += 1)
                         {
+                            if (j >= TR) break;
                             const double diffuse_pi = row_d[j], glossy = row_g[j];
                             double throughput = tail_state[(2u * j) * 64u], dst = tail_state[(2u * j + 1u) * 64u];
                             double contribution = 0.0;
@@ -1011,8 +1016,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
                          * (src/bdsf.c:121-132) -- as bdsf_at_wavelength() in drt_shade_kernel */
                         const double *row_m = l_spd_tail + ((uint32_t)mat.mirror_spd & 0xFFFFu) * TR;
                         const double *row_e = l_spd_tail + t_em * TR;
-                        for (uint32_t j = 0; j < TR; j += 1)
+#pragma unroll
+                        for (uint32_t j = 0; j < DRT_TRACE_TAIL_MAX; j += 1)
                         {
+                            if (j >= TR) break;
                             const double mirror = row_m[j];
                             double throughput = tail_state[(2u * j) * 64u], dst = tail_state[(2u * j + 1u) * 64u];
                             double contribution = 0.0;
@@ -1313,8 +1320,10 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
                 h1 = h[1];
                 h2 = h[2];
             }
-            const bool has_path = valid && (h0 & 0xFFFFu) != 0u;
-            if (valid && !has_path)
+            /* a path whose tail wavelengths the trace kernel has carried itself is done: its values are in tail_stage already */
+            const bool staged = ((uint32_t)(h0 >> 16) & HDR_TERM_TAIL_STAGED) != 0u;
+            const bool has_path = valid && !staged && (h0 & 0xFFFFu) != 0u;
+            if (valid && !staged && !has_path)
             {
                 /* no vertex: the sample is what the path ended on, with throughput 1 and nothing gathered (:452-457, :615) */
                 const bool emissive = ((uint32_t)(h0 >> 16) & HDR_TERM_MASK) == 1u;

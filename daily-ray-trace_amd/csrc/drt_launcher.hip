@@ -84,7 +84,9 @@ struct drt_context
     int         primary_grid_cap = 0, bounce_grid_cap = 0;
     double   *d_xyz = nullptr;
     uint8_t  *d_bgra = nullptr;
-    bool      trace_tail = false;     /* the trace kernel carries the tail wavelengths of every path (drt_trace_kernel<true, true>) */
+    bool      trace_tail = false;     /* the trace kernel carries the tail wavelengths of the paths it can (drt_trace_kernel<true, true>): those of plastic
+                                         and mirror vertices only, and those without a vertex */
+    bool      tail_all_staged = false; /* ... and in this scene that is every path: the shade kernel's tail pass has nothing to replay */
     const double *d_spd_tail = nullptr; /* [n_spd][tail_count]: the SPD table's tail columns */
 
     bool   scene_in_lds = true, spds_in_lds = true, use_bvh = false;
@@ -628,8 +630,13 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene, double r
             const bool mirror_only = m.num_bdsfs == 1u && m.bdsfs[0] == DRT_BDSF_mirror_bdsf;
             if (!(m.is_black_body || (m.vertex_flags & FLAG_PLASTIC) || mirror_only)) all_simple = false;
         }
+        /* DRT_TRACE_TAIL: 0 = never (every path's tail through the shade kernel's tail pass), 2 = only in scenes where every path can be
+         * carried (round 2's rule); default: whenever the kernel can run -- paths that meet glass or gold stay with the tail pass, which
+         * takes them as tasks while the others, three quarters and more, cost it nothing */
         const char *e = getenv("DRT_TRACE_TAIL");
-        ctx->trace_tail = ctx->scene_in_lds && sets == 1 && tc > 0 && tc <= 8 && n_lights == 1 && all_simple && ctx->trace_lds + extra <= 48 * 1024 && !(e && *e == '0');
+        ctx->trace_tail = ctx->scene_in_lds && sets == 1 && tc > 0 && tc <= 8 && n_lights == 1 && ctx->trace_lds + extra <= 48 * 1024 && !(e && *e == '0') &&
+                          (all_simple || !(e && *e == '2'));
+        ctx->tail_all_staged = ctx->trace_tail && all_simple;
         if (ctx->trace_tail)
         {
             std::vector<double> cols((size_t)d.n_spd * tc);
@@ -1195,7 +1202,7 @@ static int enqueue_pair(drt_context *ctx, uint32_t first_sample, uint32_t n, uin
     sp.tail_count = ctx->tail_count;
     sp.tail_stage = ctx->d_tail_stage;
     sp.light0_em_spd = ctx->light0_em_spd;
-    sp.tail_staged = (ctx->trace_tail && ctx->d_tail_stage) ? 1u : 0u;
+    sp.tail_staged = (ctx->tail_all_staged && ctx->d_tail_stage) ? 1u : 0u;
     if (const char *e = getenv("DRT_DEBUG_SHADE_MODE")) sp.mode = (uint32_t)atoi(e); /* timing probe: 1 main pass only, 2 tail pass only */
     if (const char *e = getenv("DRT_DEBUG_TAIL_PHASE_A_OFF")) sp.tail_staged = (uint32_t)atoi(e) ? 1u : sp.tail_staged;
     sp.cmf_rw = ctx->cmf_rw; sp.cmf_x = ctx->cmf_x; sp.cmf_y = ctx->cmf_y; sp.cmf_z = ctx->cmf_z;

@@ -906,13 +906,16 @@ def _counts(st):
 TAIL_GRIDS = {69: (380.0, 720.0, 5.0), 65: (380.0, 700.0, 5.0), 70: (400.0, 676.0, 4.0), 72: (400.0, 684.0, 4.0)}
 
 
-@pytest.mark.parametrize("scene,size,spp,depth", [("cornell_large_box.scn", 24, 3, 16), ("cornell_downward.scn", 20, 3, 6), ("first_scene.scn", 20, 3, 4)])
+@pytest.mark.parametrize("scene,size,spp,depth", [("cornell_large_box.scn", 24, 3, 16), ("cornell_downward.scn", 20, 3, 6), ("first_scene.scn", 20, 3, 4),
+                                                  ("cornell_plane_light.scn", 28, 4, 8), ("cornell_gold_mirror.scn", 24, 3, 8)])
 @pytest.mark.parametrize("S", list(TAIL_GRIDS))
 def test_tail_wavelengths_in_the_trace_kernel_equal_the_tail_pass(scene, size, spp, depth, S, monkeypatch):
-    """All-plastic scenes are traced by drt_trace_kernel<true, true>, which carries every path's tail wavelengths itself
-    (Stats.path_flags says so); DRT_TRACE_TAIL=0 sends the same scene through the general kernel and the shade kernel's tail
-    pass. Film, hit indices, XYZ and statistics must be the same BIT FOR BIT, in the spectral and the XYZ film, for every
-    tail width, and both must be the oracle's. (cornell_downward has the mirror, first_scene the point light and no box.)"""
+    """One-light scenes scanned out of LDS are traced by drt_trace_kernel<true, true>, which carries the tail wavelengths of the
+    paths it can itself (Stats.path_flags says so): every path in an all-plastic scene, and in a scene with glass or gold the paths
+    that never meet them -- the others stay with the shade kernel's tail pass, which takes them as tasks. DRT_TRACE_TAIL=0 sends
+    every path's tail through the tail pass. Film, hit indices, XYZ and statistics must be the same BIT FOR BIT, in the spectral
+    and the XYZ film, for every tail width, and both must be the oracle's. (cornell_downward has the mirror, first_scene the point
+    light and no box, cornell_plane_light glass + rough gold + mirror, cornell_gold_mirror smooth gold.)"""
     grid = TAIL_GRIDS[S]
     bundle = pydrt.load_scene(cases.scene_path(scene), size, size, min_wl=grid[0], max_wl=grid[1], wl_interval=grid[2])
     assert bundle.S == S
