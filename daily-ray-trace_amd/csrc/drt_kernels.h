@@ -870,11 +870,15 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
                 vis0_mask = 0;
                 tail_ok = tail_on;
                 if (tail_on)
-                    for (uint32_t j = 0; j < TR; j += 1)
+                {
+#pragma unroll
+                    for (uint32_t j = 0; j < DRT_TRACE_TAIL_MAX; j += 1)
                     {
+                        if (j >= TR) break;
                         tail_state[(2u * j) * 64u] = 1.0;      /* throughput, const_spectrum(throughput, 1.0), :440 */
                         tail_state[(2u * j + 1u) * 64u] = 0.0; /* dst */
                     }
+                }
                 uint64_t slot = q * (uint64_t)tp.batch + s_local;
                 hdr = headers + slot * REC_HEADER_WORDS;
                 /* vignette: dot(ray_direction, forward) of the PRIMARY ray, src/daily_ray_trace.c:614 */
@@ -1064,8 +1068,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
                     const double vignette = __longlong_as_double((long long)hdr[1]);
                     double *st = tp.tail_stage + (uint64_t)(hdr - headers) / REC_HEADER_WORDS * TR;
                     const double *row_t = l_spd_tail + (term_spd & 0xFFFFu) * TR;
-                    for (uint32_t j = 0; j < TR; j += 1)
+#pragma unroll
+                    for (uint32_t j = 0; j < DRT_TRACE_TAIL_MAX; j += 1)
                     {
+                        if (j >= TR) break;
                         double dst = tail_state[(2u * j + 1u) * 64u];
                         if (term == 1) dst = dst + tail_state[(2u * j) * 64u] * row_t[j];
                         st[j] = dst * vignette;
