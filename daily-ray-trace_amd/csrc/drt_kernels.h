@@ -1555,7 +1555,7 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
 }
 
 
-template <int NSETS, bool SPDS_IN_LDS, bool XYZ>
+template <int NSETS, bool SPDS_IN_LDS, bool XYZ, bool DARK>
 __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void drt_shade_kernel(DevScene sc, ShadeParams sp, const uint64_t *__restrict__ records,
                                                                  const uint64_t *__restrict__ headers, double *__restrict__ film_pixels,
                                                                  double *__restrict__ film_avgs, double *__restrict__ film_vars,
@@ -1658,6 +1658,21 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
             f_avg[k] = (active && !XYZ) ? pa[lam] : 0.0;
             f_var[k] = (active && !XYZ) ? pv[lam] : 0.0;
         }
+        /* A pixel nothing has reached yet: every accumulator is +0 (bit pattern zero). A sample worth +0 or -0 then changes nothing
+         * -- sum 0 + (+-0) = +0; mean: (+-0 - 0) / n = +-0, 0 + (+-0) = +0; variance: (+-0)(+-0) = +0, 0 + 0 = +0 -- so its update
+         * (seven f64 operations, one of them a division) is skipped, exactly. The camera rays of most pixels that see nothing all
+         * leave the scene: three samples in five on the Cornell frame, more among the 10 000 spheres. (DARK: an instantiation of its
+         * own -- in a closed scene, where no pixel stays dark, the same loop with the test in it measured 2-3 % slower; the launcher
+         * chooses by the vertices per path it measures when the context is created.) */
+        bool dark = false;
+        if (DARK)
+        {
+            bool some = false;
+#pragma unroll
+            for (int k = 0; k < NSETS; k += 1)
+                some = some || ((uint64_t)__double_as_longlong(f_sum[k]) | (uint64_t)__double_as_longlong(f_avg[k]) | (uint64_t)__double_as_longlong(f_var[k])) != 0ull;
+            dark = !__any(some);
+        }
         /* the pixel's samples in windows of 64: the headers of a window arrive in one coalesced load, lane s <- sample s */
       for (uint32_t s0 = 0; s0 < sp.n_samples; s0 += 64u)
       {
@@ -1672,6 +1687,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
             h2 = h[2];
             h3 = h[3];
         }
+        /* the window's samples that are worth +-0 whatever the wavelength: no vertex, ended on nothing that emits, and a finite vignette
+         * (0 x vignette must be a zero: a NaN or an infinity has to go through the arithmetic) -- one ballot over the headers */
+        const unsigned long long worthless = !DARK ? 0ull : __ballot(lane < n_win && (h0 & 0xFFFFu) == 0ull && ((uint32_t)(h0 >> 16) & HDR_TERM_MASK) != 1u &&
+                                                                      __builtin_isfinite(word_as_double(h1)));
         /* The first vertices of a path as the prefetch registers see them: register k, lane l holds word 64 k + l of the path's
          * vertices laid end to end. A block is four vertices, 64 words or more, so a register never straddles blocks: one block
          * number per register, from the header (scalar), and consecutive lanes read consecutive words. Only the header's own
@@ -1727,6 +1746,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                 for (int k = 0; k < SHADE_PREFETCH_REGS; k += 1) slot_now[64u * k + lane] = ring[0][k];
             }
             const uint64_t *rec_words = rec_lds + (s & 1u) * (64u * SHADE_PREFETCH_REGS);
+            /* nothing gathered, nothing emitted, into a pixel that is all +0: the film update would change no bit */
+            if (DARK && dark && ((worthless >> s) & 1ull) != 0ull) continue;
 
             double throughput[NSETS], dst[NSETS];
 #pragma unroll
@@ -1993,6 +2014,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                 }
             }
             const double denom = (double)(sp.first_sample + s0 + s + 1);
+            if (DARK) dark = false; /* (a sample that gets this far may leave something in the accumulators) */
 #pragma unroll
             for (int k = 0; k < NSETS; k += 1)
             {

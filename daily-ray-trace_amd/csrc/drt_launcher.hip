@@ -87,6 +87,7 @@ struct drt_context
     bool      trace_tail = false;     /* the trace kernel carries the tail wavelengths of the paths it can (drt_trace_kernel<true, true>): those of plastic
                                          and mirror vertices only, and those without a vertex */
     bool      tail_all_staged = false; /* ... and in this scene that is every path: the shade kernel's tail pass has nothing to replay */
+    bool      dark_skip = true;        /* the shade kernel's instantiation that passes over samples worth 0 in pixels nothing has reached yet */
     const double *d_spd_tail = nullptr; /* [n_spd][tail_count]: the SPD table's tail columns */
 
     bool   scene_in_lds = true, spds_in_lds = true, use_bvh = false;
@@ -652,12 +653,14 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene, double r
 template <int NSETS, bool XYZ>
 static int launch_shade_mode(drt_context *ctx, uint32_t grid, const ShadeParams &sp, double *const film[3])
 {
-    if (ctx->spds_in_lds)
-        hipLaunchKernelGGL((drt_shade_kernel<NSETS, true, XYZ>), dim3(grid), dim3(SHADE_BLOCK), ctx->shade_lds, ctx->stream, ctx->dsc, sp,
-                           ctx->d_records, ctx->d_headers, film[0], film[1], film[2], ctx->d_counters + DRT_NUM_COUNTERS + 1);
-    else
-        hipLaunchKernelGGL((drt_shade_kernel<NSETS, false, XYZ>), dim3(grid), dim3(SHADE_BLOCK), ctx->shade_lds, ctx->stream, ctx->dsc, sp,
-                           ctx->d_records, ctx->d_headers, film[0], film[1], film[2], ctx->d_counters + DRT_NUM_COUNTERS + 1);
+#define DRT_LAUNCH_SHADE(LDS, DARK)                                                                                                       \
+    hipLaunchKernelGGL((drt_shade_kernel<NSETS, LDS, XYZ, DARK>), dim3(grid), dim3(SHADE_BLOCK), ctx->shade_lds, ctx->stream, ctx->dsc, sp, \
+                       ctx->d_records, ctx->d_headers, film[0], film[1], film[2], ctx->d_counters + DRT_NUM_COUNTERS + 1)
+    if (ctx->spds_in_lds && ctx->dark_skip) DRT_LAUNCH_SHADE(true, true);
+    else if (ctx->spds_in_lds) DRT_LAUNCH_SHADE(true, false);
+    else if (ctx->dark_skip) DRT_LAUNCH_SHADE(false, true);
+    else DRT_LAUNCH_SHADE(false, false);
+#undef DRT_LAUNCH_SHADE
     return 0;
 }
 
@@ -698,10 +701,11 @@ static int launch_shade(drt_context *ctx, uint32_t grid, const ShadeParams &sp, 
 template <int NSETS, bool XYZ>
 static int shade_occupancy_mode(drt_context *ctx, int *per_cu)
 {
+    /* (the DARK instantiations have the same registers and LDS) */
     if (ctx->spds_in_lds)
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, drt_shade_kernel<NSETS, true, XYZ>, SHADE_BLOCK, ctx->shade_lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, drt_shade_kernel<NSETS, true, XYZ, true>, SHADE_BLOCK, ctx->shade_lds));
     else
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, drt_shade_kernel<NSETS, false, XYZ>, SHADE_BLOCK, ctx->shade_lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, drt_shade_kernel<NSETS, false, XYZ, true>, SHADE_BLOCK, ctx->shade_lds));
     return 0;
 }
 
@@ -922,6 +926,13 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
         HIP_TRY(hipMemcpyAsync(&used, ctx->d_counters + DRT_PAIR_COUNTERS + 5, sizeof(used), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         ctx->est_blocks_per_path = (double)used / (double)n_sample;
+        {
+            /* vertices per path on the sample: a scene whose paths average three vertices and more is a closed one -- hardly a pixel
+             * stays dark there, and the shade kernel without the test for it is the faster one (config 3: 1767 against 1806-1837 ms) */
+            unsigned long long cnt[3] = {0, 0, 0}; /* paths, scans, shaded vertices of the sample */
+            HIP_TRY(hipMemcpy(cnt, ctx->d_counters + DRT_PAIR_COUNTERS, sizeof(cnt), hipMemcpyDeviceToHost));
+            if (cnt[0] > 0) ctx->dark_skip = (double)cnt[2] / (double)cnt[0] < 3.0;
+        }
         (void)hipFree(ctx->d_records); ctx->d_records = nullptr;
         (void)hipFree(ctx->d_headers); ctx->d_headers = nullptr;
         (void)hipFree(ctx->d_primary); ctx->d_primary = nullptr;
@@ -979,6 +990,7 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
         HIP_TRY(hipMalloc((void **)&ctx->d_queue, (size_t)npx * batch * sizeof(uint64_t)));
     }
     if (ctx->tail_count) HIP_TRY(hipMalloc((void **)&ctx->d_tail_stage, (size_t)npx * batch * ctx->tail_count * 8));
+    if (const char *e = getenv("DRT_DARK_SKIP")) ctx->dark_skip = atoi(e) != 0; /* A/B switch of the parity tests: same film either way */
     if (getenv("DRT_VERBOSE"))
         fprintf(stderr, "drt: %d CUs, trace %d blocks/CU (lds %zu), shade %d blocks/CU (lds %zu), batch %u, %.3f blocks/path measured (worst %u), pool %.2f GB\n",
                 prop.multiProcessorCount, per_cu, ctx->trace_lds, s_per_cu, ctx->shade_lds, ctx->batch_spp, ctx->est_blocks_per_path,

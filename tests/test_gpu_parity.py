@@ -1260,3 +1260,27 @@ def test_fresnel_rows_on_random_scenes_with_nested_media(seed, monkeypatch):
     b = _render_all(bundle, params)
     monkeypatch.delenv("DRT_NO_PAIR_ROWS")
     assert all(fuzz_scenes.same(x, y) for x, y in zip(a[0], b[0])) and np.array_equal(a[1], b[1]) and _counts(a[3]) == _counts(b[3])
+
+
+@pytest.mark.parametrize("name", ["plane_light_48", "first_scene", "lights", "grid_2p5nm", "spheres_1500"])
+def test_dark_pixel_shortcut_changes_no_bit(name, monkeypatch):
+    """The shade kernel passes over a sample that gathered and emitted nothing when every accumulator of the pixel is still +0 (the
+    update would add +-0 to zeros). The launcher picks that instantiation unless the scene is a closed one (DRT_DARK_SKIP=0 / 1 forces
+    the choice): film, XYZ and statistics are the same bit for bit either way, in the spectral and the XYZ film, also when the film
+    is carried over from an earlier call (then pixels are no longer dark) and when samples come in several launches."""
+    bundle, params = cases.load_case(name)
+    for mode in (pydrt.MODE_SPECTRAL, pydrt.MODE_XYZ):
+        got = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("DRT_DARK_SKIP", flag)
+            p = pydrt.make_params(int(params.width), int(params.height), spp=int(params.spp) + 3, max_depth=int(params.max_depth), seed=int(params.seed),
+                                  pixel_scheme=int(params.pixel_scheme), mode=mode, batch_spp=2)
+            r = pydrt.Renderer(bundle, p)
+            r.render(0, 2)
+            r.render(2, int(params.spp) + 1)
+            film = (r.read_xyz_film(),) if mode == pydrt.MODE_XYZ else r.read_film()
+            got.append((film, r.read_xyz(), r.stats()))
+            r.close()
+        monkeypatch.delenv("DRT_DARK_SKIP")
+        assert all(fuzz_scenes.same(a, b) for a, b in zip(got[0][0], got[1][0])), (name, mode)
+        assert fuzz_scenes.same(got[0][1], got[1][1]) and _counts(got[0][2]) == _counts(got[1][2])
