@@ -1691,6 +1691,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
          * (0 x vignette must be a zero: a NaN or an infinity has to go through the arithmetic) -- one ballot over the headers */
         const unsigned long long worthless = !DARK ? 0ull : __ballot(lane < n_win && (h0 & 0xFFFFu) == 0ull && ((uint32_t)(h0 >> 16) & HDR_TERM_MASK) != 1u &&
                                                                       __builtin_isfinite(word_as_double(h1)));
+        /* a whole window of them in a pixel that is still dark: nothing to do for any of its samples */
+        if (DARK && dark && (uint32_t)__popcll(worthless) == n_win) continue;
         /* The first vertices of a path as the prefetch registers see them: register k, lane l holds word 64 k + l of the path's
          * vertices laid end to end. A block is four vertices, 64 words or more, so a register never straddles blocks: one block
          * number per register, from the header (scalar), and consecutive lanes read consecutive words. Only the header's own
