@@ -19,4 +19,5 @@ for seed in range(first, last + 1):
     if not ok:
         bad.append(seed)
         print("MISMATCH seed", seed, "hits differ:", int((hits != ohits).any(axis=1).sum()), flush=True)
+    if (seed - first) % 500 == 499: print("... seed %d, %d mismatches, %.1f s" % (seed, len(bad), time.time() - t0), flush=True)
 print("seeds %d..%d: %d scenes, %d mismatches %s, %.1f s" % (first, last, last - first + 1, len(bad), bad, time.time() - t0))
