@@ -1314,7 +1314,10 @@ static int enqueue_blocks(drt_context *ctx, uint32_t first_sample, uint32_t num_
 {
     const uint32_t H = ctx->params.tile_h, W = ctx->params.tile_w;
     const uint32_t per = (H + n_blocks - 1) / n_blocks;
-    const uint32_t n_blk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(num_samples, 4096), ctx->n_pix * (uint64_t)ctx->batch_spp * 5 / 8 / ((uint64_t)per * W)));
+    const uint32_t fit = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(num_samples, 4096), ctx->n_pix * (uint64_t)ctx->batch_spp * 5 / 8 / ((uint64_t)per * W)));
+    /* ... in pairs of equal size: 256 samples where 125 fit go out as 86 + 85 + 85, not 125 + 125 + 6 (a launch of 6 samples fills the chip for a moment only) */
+    const uint32_t n_pairs = (num_samples + fit - 1) / fit;
+    const uint32_t n_blk = n_pairs ? (num_samples + n_pairs - 1) / n_pairs : 1u;
     for (uint32_t r0 = 0; r0 < H; r0 += per)
     {
         const uint32_t rows = std::min(per, H - r0);
@@ -1370,9 +1373,12 @@ extern "C" int drt_render(drt_context *ctx, uint32_t first_sample, uint32_t num_
         const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(want, 16), p.tile_h / 16);
         if (n_blocks > 1) return enqueue_blocks(ctx, first_sample, num_samples, n_blocks, nullptr);
     }
-    for (uint32_t done = 0; done < num_samples; done += ctx->batch_spp)
+    /* (pairs of equal size here too: 100 samples where 64 fit are 50 + 50) */
+    const uint32_t n_pairs = (num_samples + ctx->batch_spp - 1) / ctx->batch_spp;
+    const uint32_t each = n_pairs ? (num_samples + n_pairs - 1) / n_pairs : 1u;
+    for (uint32_t done = 0; done < num_samples; done += each)
     {
-        int rc = enqueue_pair(ctx, first_sample + done, std::min(ctx->batch_spp, num_samples - done), done);
+        int rc = enqueue_pair(ctx, first_sample + done, std::min(each, num_samples - done), done);
         if (rc) return rc;
     }
     return 0;

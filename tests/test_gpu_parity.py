@@ -44,6 +44,15 @@ def test_device_arithmetic_is_ieee_and_matches_the_oracle_spec():
     assert np.array_equal(pydrt.selftest_arith(0, a), np.sqrt(a)), "f64 sqrt is not correctly rounded"
     with np.errstate(over="ignore", under="ignore"):
         assert np.array_equal(pydrt.selftest_arith(1, a, b), a / b), "f64 divide is not correctly rounded"
+    # The one place gfx950's division is NOT the IEEE quotient: results in the SUBNORMAL range (|q| < 2^-1022), where its scaled
+    # sequence rounds twice -- a few quotients per million come out one unit (2^-1074) off, never more. No radiance, mean or variance
+    # of a film is anywhere near 1e-308 (and the film tolerance is relative to the frame's brightest value), so the chain of evidence
+    # of DESIGN.md section 2 is not touched; it is stated and bounded here rather than left to be found.
+    sub_a = (rng.integers(1 << 40, 1 << 52, 2_000_000, dtype=np.uint64) << np.uint64(0)).view(np.float64) * rng.choice([-1.0, 1.0], 2_000_000)
+    sub_b = rng.integers(2, 4097, 2_000_000).astype(np.float64)
+    got, want = pydrt.selftest_arith(1, sub_a, sub_b), sub_a / sub_b
+    off = np.abs(got.view(np.int64) - want.view(np.int64))
+    assert off.max() <= 1 and np.count_nonzero(off) <= 40, (int(off.max()), int(np.count_nonzero(off)))
     t = np.concatenate([rng.uniform(-1.0, 7.0, 20000), [0.0, np.pi / 4, np.pi / 2, np.pi, 2 * np.pi, 3 * np.pi / 4]])
     sc = pydrt.selftest_arith(2, t).reshape(-1, 2)
     L = O.oracle_lib()
@@ -1007,7 +1016,7 @@ def test_tail_in_trace_kernel_on_tiles_groups_row_blocks_and_a_pool_that_runs_ou
     monkeypatch.delenv("DRT_ONESHOT_BLOCKS")
     assert redo[3].redone_launches >= 1 and same_films(redo[:3], on[:3]) and _counts(redo[3]) == _counts(on[3])
     # a session whose pool runs out in the middle of several queued pairs, hit log on
-    ps = pydrt.make_params(40, 33, spp=9, max_depth=16, seed=9, batch_spp=4)
+    ps = pydrt.make_params(40, 33, spp=12, max_depth=16, seed=9, batch_spp=4)  # three pairs of four samples
     small = _render_all(box, ps)
     monkeypatch.delenv("DRT_POOL_BLOCKS")
     roomy = _render_all(box, ps)
@@ -1027,6 +1036,19 @@ def test_config1_at_its_stated_size_whole_frame():
     assert cases.xyz_rel_err(xyz, O.oracle_film_to_xyz(bundle, opx)) <= XYZ_TOL
     assert st.path_flags & pydrt.PATH_TRACE_TAIL  # the legacy scene is all plastic: this is the trace_tail path
     assert st.launches >= 1 and 0.0 < st.min_sample_ms <= st.avg_sample_ms <= st.max_sample_ms
+
+
+def test_config2_frame_at_full_width_every_path_against_the_oracle():
+    """BASELINE configs[1]'s frame -- cornell_plane_light.scn 1024x1024, depth 8 -- at 2 samples per pixel, WHOLE: every hit index
+    of all 2 097 152 paths, the statistics and the whole film against the oracle (the 256-spp run of this frame is checked through
+    probe pixels and invariants; this one leaves no pixel of the full-width frame unchecked)."""
+    bundle = pydrt.load_scene(cases.scene_path("cornell_plane_light.scn"), 1024, 1024)
+    p = pydrt.make_params(1024, 1024, spp=2, max_depth=8, seed=1)
+    film, hits, xyz, st = _render_all(bundle, p)
+    opx, oav, ova, ohits, ost = O.oracle_render_tile(bundle, p, want_hits=True, math_mode=O.MATH_DEVICE, num_threads=16)
+    assert st.paths == 1024 * 1024 * 2 and np.array_equal(hits, ohits) and _counts(st) == _counts(ost)
+    assert cases.rel_err(film[0], opx) <= FILM_TOL and cases.rel_err(film[1], oav) <= FILM_TOL and cases.rel_err(film[2], ova) <= FILM_TOL
+    assert cases.xyz_rel_err(xyz, O.oracle_film_to_xyz(bundle, opx)) <= XYZ_TOL
 
 
 @pytest.mark.parametrize("name", list(cases.NAN_CASES))
