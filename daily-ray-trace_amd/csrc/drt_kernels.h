@@ -1108,6 +1108,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
 #define DRT_SHADE_WAVES_MULTISET(n) ((n) == 2 ? 3 : 2)
 #endif
 #define SHADE_WAVES_PER_SIMD_FOR(n) ((n) == 1 ? DRT_SHADE_WAVES_PER_SIMD : DRT_SHADE_WAVES_MULTISET(n))
+#ifndef DRT_SHADE_WAVES_SIMPLE
+#define DRT_SHADE_WAVES_SIMPLE 5 /* the SIMPLE instantiation (no Fresnel code): 5 waves per SIMD without a spill; 6 (80 registers, 40 bytes of scratch)
+                                    measured the same (config 3: shade 1772 -> 1692 ms at 6, 1691 at 5) */
+#endif
 #define SHADE_MAX_SETS 4 /* wavelengths per lane: S <= 64 * SHADE_MAX_SETS */
 
 struct ShadeParams
@@ -1160,6 +1164,11 @@ __device__ __forceinline__ double spd_at(SpdPtr spds, uint32_t S, uint32_t idx, 
  * once and carried from function to function; functions whose direction test fails leave it (Q1). */
 /* `paired`: the vertex's pair of media has tabulated rows (fresnel_rows): then te is rel_sq for the dielectric functions, and
  * (ir, tr) are (cA, cB) for the conductor functions -- the *_sel forms of drt_device.h, same bits with fewer divisions. */
+/* SIMPLE: an instantiation for scenes whose materials list nothing but bp_diffuse_bdsf, bp_glossy_bdsf and mirror_bdsf (the launcher
+ * checks): the Fresnel cases, their divisions and square roots and the registers they live in are not compiled in, and the shade kernel
+ * that is left fits five waves per SIMD instead of four (config 3, all plastic: shade 1772 -> 1691 ms). Same bits: the cases left
+ * are the same code (tests/test_gpu_parity.py flips DRT_NO_SIMPLE_SHADE). */
+template <bool SIMPLE = false>
 __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num_bdsfs, double diffuse_pi, double glossy, double mirror,
                                                      double ir, double tr, double te, double on_dot, double a_in, double spec,
                                                      double mn_dot, double ct_coef, uint32_t flags, bool paired)
@@ -1184,6 +1193,7 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
                 bdsf_result = (flags & FLAG_EQR) ? mirror : 0.0;
                 break;
             case DRT_BDSF_fs_conductor_bdsf: /* :134-146 */
+                if (SIMPLE) break;
                 if (flags & FLAG_EQR)
                 {
                     DRT_PIN_HERE(ir);
@@ -1192,6 +1202,7 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
                 }
                 break;
             case DRT_BDSF_fs_dielectric_reflectance_bdsf: /* :148-159 */
+                if (SIMPLE) break;
                 if (flags & FLAG_EQR)
                 {
                     DRT_PIN_HERE(ir);
@@ -1199,6 +1210,7 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
                 }
                 break;
             case DRT_BDSF_fs_dielectric_transmittance_bdsf: /* :161-172, :69-76 */
+                if (SIMPLE) break;
                 if (flags & FLAG_EQT)
                 {
                     DRT_PIN_HERE(ir);
@@ -1207,6 +1219,7 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
                 break;
             case DRT_BDSF_ct_conductor_bdsf: /* :174-186 */
             {
+                if (SIMPLE) break;
                 DRT_PIN_HERE(ir);
                 double c2 = mn_dot * mn_dot;
                 bdsf_result = conductor_reflectance_sel(paired, ir, tr, te, mn_dot, c2, 1.0 - c2) * ct_coef;
@@ -1255,7 +1268,7 @@ __device__ __forceinline__ double bdsf_at_wavelength(uint64_t list, uint32_t num
  * arithmetic in the same order. It is a work item of the shade kernel's queue, sharing the SIMDs with main-pass waves
  * (as a kernel of its own, at 4 to 8 waves per SIMD, it was 12-27 ms slower: measured).
  */
-template <bool SPDS_IN_LDS, bool XYZ>
+template <bool SPDS_IN_LDS, bool XYZ, bool SIMPLE>
 __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const ShadeParams &sp, const double *lds, uint64_t *wave_lds, const uint64_t *__restrict__ records,
                                                  const uint64_t *__restrict__ headers, double *__restrict__ film_pixels,
                                                  double *__restrict__ film_avgs, double *__restrict__ film_vars, uint64_t chunk_base,
@@ -1467,7 +1480,7 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
                     uint32_t f0, f1, f2;
                     bool paired;
                     fresnel_rows(w2, f0, f1, f2, paired);
-                    const double ir = spd_at(table, S, f0, lam), tr = spd_at(table, S, f1, lam), te = spd_at(table, S, f2, lam);
+                    const double ir = SIMPLE ? 0.0 : spd_at(table, S, f0, lam), tr = SIMPLE ? 0.0 : spd_at(table, S, f1, lam), te = SIMPLE ? 0.0 : spd_at(table, S, f2, lam);
                     double contribution = 0.0;
                     for (uint32_t l = 0; l < sp.n_lights; l += 1)
                     {
@@ -1475,7 +1488,7 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
                         const uint64_t lw0 = lrec[0];
                         const uint32_t lflags = (uint32_t)(lw0 >> 16) & 0xFFu;
                         if (!(lflags & FLAG_VISIBLE)) continue;
-                        double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse_pi, glossy, mirror, ir, tr, te, on_dot,
+                        double reflectance = bdsf_at_wavelength<SIMPLE>(list, num_bdsfs, diffuse_pi, glossy, mirror, ir, tr, te, on_dot,
                                                                 word_as_double(lrec[2]), word_as_double(lrec[3]), word_as_double(lrec[4]),
                                                                 word_as_double(lrec[5]), lflags, paired);
                         contribution = contribution + reflectance;
@@ -1483,7 +1496,7 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
                         contribution = contribution * word_as_double(lrec[1]);
                     }
                     dst = dst + throughput * contribution;
-                    double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse_pi, glossy, mirror, ir, tr, te, on_dot, s_a_in, s_spec,
+                    double reflectance = bdsf_at_wavelength<SIMPLE>(list, num_bdsfs, diffuse_pi, glossy, mirror, ir, tr, te, on_dot, s_a_in, s_spec,
                                                             word_as_double(vrec[7]), word_as_double(vrec[8]), sflags, paired);
                     reflectance = reflectance * dir_pdf;
                     throughput = throughput * reflectance;
@@ -1555,8 +1568,8 @@ __device__ __forceinline__ void shade_tail_group(const DevScene &sc, const Shade
 }
 
 
-template <int NSETS, bool SPDS_IN_LDS, bool XYZ, bool DARK>
-__global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void drt_shade_kernel(DevScene sc, ShadeParams sp, const uint64_t *__restrict__ records,
+template <int NSETS, bool SPDS_IN_LDS, bool XYZ, bool DARK, bool SIMPLE = false>
+__global__ __launch_bounds__(SHADE_BLOCK, (SIMPLE && NSETS == 1) ? DRT_SHADE_WAVES_SIMPLE : SHADE_WAVES_PER_SIMD_FOR(NSETS)) void drt_shade_kernel(DevScene sc, ShadeParams sp, const uint64_t *__restrict__ records,
                                                                  const uint64_t *__restrict__ headers, double *__restrict__ film_pixels,
                                                                  double *__restrict__ film_avgs, double *__restrict__ film_vars,
                                                                  unsigned long long *__restrict__ work_counter)
@@ -1970,8 +1983,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                 for (int k = 0; k < NSETS; k += 1)
                 {
                     diffuse[k] = spd_at(table, S, i_diffuse, lam_c[k]); glossy[k] = spd_at(table, S, i_glossy, lam_c[k]);
-                    mirror[k] = spd_at(table, S, i_mirror, lam_c[k]);   ir[k] = spd_at(table, S, i_ir, lam_c[k]);
-                    tr[k] = spd_at(table, S, i_tr, lam_c[k]);           te[k] = spd_at(table, S, i_te, lam_c[k]);
+                    mirror[k] = spd_at(table, S, i_mirror, lam_c[k]);   ir[k] = SIMPLE ? 0.0 : spd_at(table, S, i_ir, lam_c[k]);
+                    tr[k] = SIMPLE ? 0.0 : spd_at(table, S, i_tr, lam_c[k]); te[k] = SIMPLE ? 0.0 : spd_at(table, S, i_te, lam_c[k]);
                 }
                 for (uint32_t l = 0; l < sp.n_lights; l += 1) /* direct_light_contribution, :272-332 */
                 {
@@ -1996,7 +2009,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
 #pragma unroll
                     for (int k = 0; k < NSETS; k += 1)
                     {
-                        double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse[k], glossy[k], mirror[k], ir[k], tr[k], te[k], on_dot,
+                        double reflectance = bdsf_at_wavelength<SIMPLE>(list, num_bdsfs, diffuse[k], glossy[k], mirror[k], ir[k], tr[k], te[k], on_dot,
                                                                 word_as_double(lw[2]), word_as_double(lw[3]), word_as_double(lw[4]),
                                                                 word_as_double(lw[5]), lflags, paired);
                         contribution[k] = contribution[k] + reflectance;                      /* :323 */
@@ -2009,7 +2022,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
                 for (int k = 0; k < NSETS; k += 1)
                 {
                     dst[k] = dst[k] + throughput[k] * contribution[k]; /* :461-462 */
-                    double reflectance = bdsf_at_wavelength(list, num_bdsfs, diffuse[k], glossy[k], mirror[k], ir[k], tr[k], te[k], on_dot,
+                    double reflectance = bdsf_at_wavelength<SIMPLE>(list, num_bdsfs, diffuse[k], glossy[k], mirror[k], ir[k], tr[k], te[k], on_dot,
                                                             s_a_in, s_spec, s_mn, s_ct, sflags, paired);
                     reflectance = reflectance * dir_pdf;         /* :468 */
                     throughput[k] = throughput[k] * reflectance; /* :469 */
@@ -2089,7 +2102,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_SIMD_FOR(NSETS)) void 
         }
       }
 
-        if (tail_item && sp.mode != 1u) shade_tail_group<SPDS_IN_LDS, XYZ>(sc, sp, (const double *)lds, rec_lds, records, headers, film_pixels, film_avgs, film_vars, chunk_base, chunk_end, lane);
+        if (tail_item && sp.mode != 1u) shade_tail_group<SPDS_IN_LDS, XYZ, SIMPLE>(sc, sp, (const double *)lds, rec_lds, records, headers, film_pixels, film_avgs, film_vars, chunk_base, chunk_end, lane);
     }
 }
 

@@ -88,6 +88,7 @@ struct drt_context
                                          and mirror vertices only, and those without a vertex */
     bool      tail_all_staged = false; /* ... and in this scene that is every path: the shade kernel's tail pass has nothing to replay */
     bool      dark_skip = true;        /* the shade kernel's instantiation that passes over samples worth 0 in pixels nothing has reached yet */
+    bool      simple_bdsfs = false;    /* no material lists anything but bp_diffuse_bdsf, bp_glossy_bdsf, mirror_bdsf: the shade kernel without the Fresnel code */
     const double *d_spd_tail = nullptr; /* [n_spd][tail_count]: the SPD table's tail columns */
 
     bool   scene_in_lds = true, spds_in_lds = true, use_bvh = false;
@@ -624,6 +625,14 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene, double r
         uint32_t sets = 0, tf = 0, tc = 0;
         shade_sets(S, &sets, &tf, &tc);
         const size_t extra = (size_t)d.n_spd * tc * 8 + (size_t)(TRACE_BLOCK / 64) * 2 * tc * 64 * 8;
+        /* every list of every material (used by a surface or not: a ray can only meet a surface's, but the check is cheap) */
+        ctx->simple_bdsfs = !getenv("DRT_NO_SIMPLE_SHADE");
+        for (uint32_t i = 0; i < scene->num_materials; i += 1)
+            for (uint32_t j = 0; j < mats[i].num_bdsfs; j += 1)
+            {
+                const uint32_t b = mats[i].bdsfs[j];
+                if (b != DRT_BDSF_bp_diffuse_bdsf && b != DRT_BDSF_bp_glossy_bdsf && b != DRT_BDSF_mirror_bdsf) ctx->simple_bdsfs = false;
+            }
         bool all_simple = true;
         for (uint32_t i = 0; i < n_surf; i += 1)
         {
@@ -650,16 +659,24 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene, double r
     return 0;
 }
 
+static bool shade_simple(const drt_context *ctx) { return ctx->simple_bdsfs && ctx->spds_in_lds && ctx->shade_sets == 1; }
+
 template <int NSETS, bool XYZ>
 static int launch_shade_mode(drt_context *ctx, uint32_t grid, const ShadeParams &sp, double *const film[3])
 {
-#define DRT_LAUNCH_SHADE(LDS, DARK)                                                                                                       \
-    hipLaunchKernelGGL((drt_shade_kernel<NSETS, LDS, XYZ, DARK>), dim3(grid), dim3(SHADE_BLOCK), ctx->shade_lds, ctx->stream, ctx->dsc, sp, \
+#define DRT_LAUNCH_SHADE(LDS, DARK, SIMPLE)                                                                                                       \
+    hipLaunchKernelGGL((drt_shade_kernel<NSETS, LDS, XYZ, DARK, SIMPLE>), dim3(grid), dim3(SHADE_BLOCK), ctx->shade_lds, ctx->stream, ctx->dsc, sp, \
                        ctx->d_records, ctx->d_headers, film[0], film[1], film[2], ctx->d_counters + DRT_NUM_COUNTERS + 1)
-    if (ctx->spds_in_lds && ctx->dark_skip) DRT_LAUNCH_SHADE(true, true);
-    else if (ctx->spds_in_lds) DRT_LAUNCH_SHADE(true, false);
-    else if (ctx->dark_skip) DRT_LAUNCH_SHADE(false, true);
-    else DRT_LAUNCH_SHADE(false, false);
+    /* SIMPLE: scenes without a Fresnel function, one wavelength set per lane, tables in LDS (shade_simple()) */
+    if (NSETS == 1 && shade_simple(ctx))
+    {
+        if (ctx->dark_skip) DRT_LAUNCH_SHADE(true, true, (NSETS == 1));
+        else DRT_LAUNCH_SHADE(true, false, (NSETS == 1));
+    }
+    else if (ctx->spds_in_lds && ctx->dark_skip) DRT_LAUNCH_SHADE(true, true, false);
+    else if (ctx->spds_in_lds) DRT_LAUNCH_SHADE(true, false, false);
+    else if (ctx->dark_skip) DRT_LAUNCH_SHADE(false, true, false);
+    else DRT_LAUNCH_SHADE(false, false, false);
 #undef DRT_LAUNCH_SHADE
     return 0;
 }
@@ -702,7 +719,9 @@ template <int NSETS, bool XYZ>
 static int shade_occupancy_mode(drt_context *ctx, int *per_cu)
 {
     /* (the DARK instantiations have the same registers and LDS) */
-    if (ctx->spds_in_lds)
+    if (NSETS == 1 && shade_simple(ctx))
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, drt_shade_kernel<NSETS, true, XYZ, true, (NSETS == 1)>, SHADE_BLOCK, ctx->shade_lds));
+    else if (ctx->spds_in_lds)
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, drt_shade_kernel<NSETS, true, XYZ, true>, SHADE_BLOCK, ctx->shade_lds));
     else
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, drt_shade_kernel<NSETS, false, XYZ, true>, SHADE_BLOCK, ctx->shade_lds));

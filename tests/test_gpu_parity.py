@@ -1024,6 +1024,30 @@ def test_tail_in_trace_kernel_on_tiles_groups_row_blocks_and_a_pool_that_runs_ou
     assert same_films(small[0], roomy[0]) and np.array_equal(small[1], roomy[1]) and _counts(small[3]) == _counts(roomy[3])
 
 
+@pytest.mark.parametrize("scene,size,spp,depth", [("cornell_large_box.scn", 40, 6, 16), ("cornell_downward.scn", 32, 5, 6), ("init_cornell.scn", 32, 4, 4), ("first_scene.scn", 24, 3, 4)])
+@pytest.mark.parametrize("mode", ["spectral", "xyz"])
+def test_shade_kernel_without_the_fresnel_code_changes_no_bit(scene, size, spp, depth, mode, monkeypatch):
+    """Scenes whose materials list only bp_diffuse_bdsf, bp_glossy_bdsf and mirror_bdsf run the shade kernel's SIMPLE instantiation (no
+    Fresnel code, five waves per SIMD: csrc/drt_kernels.h). DRT_NO_SIMPLE_SHADE=1 sends them through the general one: same film, bit for
+    bit, with the tail wavelengths in the trace kernel and (DRT_TRACE_TAIL=0) through the tail pass, whose general loop is instantiated
+    both ways too."""
+    bundle = pydrt.load_scene(cases.scene_path(scene), size, size)
+    p = pydrt.make_params(size, size, spp=spp, max_depth=depth, seed=7, mode=pydrt.MODE_XYZ if mode == "xyz" else pydrt.MODE_SPECTRAL, batch_spp=2)
+    for tail in (None, "0"):
+        if tail is None:
+            monkeypatch.delenv("DRT_TRACE_TAIL", raising=False)
+        else:
+            monkeypatch.setenv("DRT_TRACE_TAIL", tail)
+        monkeypatch.delenv("DRT_NO_SIMPLE_SHADE", raising=False)
+        simple = _render_all(bundle, p)
+        monkeypatch.setenv("DRT_NO_SIMPLE_SHADE", "1")
+        general = _render_all(bundle, p)
+        monkeypatch.delenv("DRT_NO_SIMPLE_SHADE")
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(simple[0], general[0]))
+        assert np.array_equal(simple[1], general[1]) and np.array_equal(simple[2], general[2], equal_nan=True) and _counts(simple[3]) == _counts(general[3])
+    monkeypatch.delenv("DRT_TRACE_TAIL", raising=False)
+
+
 def test_config1_at_its_stated_size_whole_frame():
     """BASELINE configs[0] exactly as named -- init_cornell.scn 256x256, 4 spp, depth 4, fixed seed -- on the HIP path: every
     hit index, the statistics and the whole film against the oracle (262 144 paths)."""
