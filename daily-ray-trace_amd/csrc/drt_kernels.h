@@ -756,11 +756,13 @@ __global__ __launch_bounds__(TRACE_BLOCK, DRT_TRACE_WAVES_PER_SIMD) void drt_tra
      * Tail wavelengths in the trace kernel. The shade kernel's lanes are wavelengths, and the S mod 64 that do not fill a wave (5 on
      * the reference grid) cost it a pass of their own in which a lane must decode records by itself. HERE a lane is a path and
      * already holds every number a vertex contributes, so the same arithmetic for those few wavelengths is a handful of f64
-     * operations per vertex at full lane use. It is done for paths that consist of two-lobe plastic vertices only (and for paths
-     * without a vertex): running throughput and radiance per tail wavelength live in LDS (a wave's block: [2 R][64 lanes]), the
-     * table's tail columns too, and when the path ends its values go to tail_stage, flagged in the header. The launcher uses this
-     * instantiation only for scenes in which EVERY material is one of the two (then the shade kernel's tail pass has no path to
-     * replay and only updates the film: ShadeParams::tail_staged); a path that met any other material would stay unflagged.
+     * operations per vertex at full lane use. It is done for paths that consist of two-lobe plastic and mirror vertices only (and
+     * for paths without a vertex): running throughput and radiance per tail wavelength live in LDS (a wave's block: [2 R][64 lanes]),
+     * the table's tail columns too, and when the path ends its values go to tail_stage, flagged in the header
+     * (HDR_TERM_TAIL_STAGED). A path that meets any other material stays unflagged and is replayed by the shade kernel's tail pass,
+     * which takes such paths as tasks and skips the flagged ones; in a scene where EVERY path is carried here the launcher says so
+     * (ShadeParams::tail_staged) and that pass only updates the film. The launcher takes this instantiation for every scene scanned
+     * out of LDS with one light and a tail of at most 8 wavelengths (DRT_TRACE_TAIL=0 turns it off, the parity tests' A/B).
      * Same operations in the same order as drt_shade_kernel's (src/daily_ray_trace.c:440-472, :615).
      */
     const uint32_t TR = tp.tail_count;

@@ -617,10 +617,10 @@ static int build_device_scene(drt_context *ctx, const drt_scene *scene, double r
     if (!ctx->scene_in_lds) ctx->trace_lds = 0;
     ctx->spds_in_lds = (size_t)d.n_spd * S * 8 <= 64 * 1024;
     /* The tail wavelengths in the trace kernel (csrc/drt_kernels.h, drt_trace_kernel<true, true>): scenes scanned out of LDS with one
-     * light and a tail of at most 8 wavelengths, in which every surface is a light, a black body, two-lobe plastic or a mirror -- so
-     * that EVERY path's tail is staged there and the shade kernel's tail pass has nothing to replay -- when the table's tail columns
-     * and the waves' running values ([2 R][64 lanes] each) fit beside the scene. (With glass or gold in the scene the paths that
-     * touch them would stay with the tail pass, and the scheme as a whole measured no gain: DESIGN.md section 7.) */
+     * light and a tail of at most 8 wavelengths, when the table's tail columns and the waves' running values ([2 R][64 lanes] each)
+     * fit beside the scene. Paths of two-lobe plastic and mirror vertices (and those without a vertex) are carried there; where
+     * every surface is a light, a black body, plastic or a mirror that is EVERY path, and the shade kernel's tail pass has nothing
+     * to replay (tail_all_staged). With glass or gold in the scene the paths that touch them stay with the tail pass, as tasks. */
     {
         uint32_t sets = 0, tf = 0, tc = 0;
         shade_sets(S, &sets, &tf, &tc);
@@ -903,9 +903,11 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
      * 28 GB instead of 68. If a launch runs out after all, its
      * shade kernel and everything queued behind it do nothing and the host renders those samples again in launches sized for the
      * worst case (redo_batches): slower, never wrong. Launch size: large launches are the efficient ones (their last round is
-     * amortised: DESIGN.md, work queues); the default follows the job announced in params->spp -- about 32 kernel pairs, at least
-     * 16 GB of records (one-shot 1024^2 x 256 spp: 926 Mpaths/s with 6 GB, 1050 with 20-30 GB, no slower to create), at most 64 M paths per launch -- because device memory a process touches for the first time is cleared by
-     * the driver (10-40 ms per GB). Callers that keep a context across many frames pass batch_spp themselves.
+     * amortised: DESIGN.md, work queues); the default (batch_spp = 0, a one-shot job) follows the job announced in params->spp -- about
+     * 32 kernel pairs, at least 16 GB of records, at most 64 M paths per launch. A larger pool would save launches (one pair per row
+     * block of the one-shot call instead of two: kernels 179 -> 171 ms with 40 GB) but a process that starts right after another has
+     * freed tens of GB waits for the driver to scrub them, 1-2 s per 40 GB (tools/r03_oneshot_blocks.sh): 16 GB stays.
+     * Callers that keep a context across many frames pass DRT_BATCH_RESIDENT (below) or a batch_spp of their own.
      */
     const size_t block_bytes = (size_t)ctx->block_words * 8;
     const uint64_t npx = std::max<uint64_t>(ctx->n_pix, 1);
@@ -970,12 +972,11 @@ static int create_impl(drt_context *ctx, const drt_scene *scene, const drt_camer
     uint32_t batch = params->batch_spp;
     if (batch == DRT_BATCH_RESIDENT)
     {
-        /* a context kept across many frames: 64 M paths per kernel pair keep the launches' last rounds short (work
-         * queues) -- but never fewer than 16 samples per pixel and launch where memory allows, because the film is read and written
-         * once per launch: 3328 bytes per pixel, which at 4 samples a launch (the 4096^2 frame of config 5) was a third of the frame */
-        /* (256 M paths where memory allows: 288 GB of HBM hold the 116 GB of records that takes on the Cornell frame, and each launch
-         * ends on a partly idle chip: 1024^2 x 256 spp in one pair instead of four, 1525 -> 1568 Mpaths/s; the loop below halves the
-         * launch until its records fit half of what is free) */
+        /* a context kept across many frames: up to 256 M paths per kernel pair -- every launch ends on a partly idle chip (work
+         * queues), and 288 GB of HBM hold the 116 GB of records that takes on the Cornell frame: 1024^2 x 256 spp in one pair instead of
+         * four, 1525 -> 1568 Mpaths/s (the loop below halves the launch until its records fit half of what is free) -- but never fewer
+         * than 16 samples per pixel and launch, because the film is read and written once per launch: 3328 bytes per pixel, which at
+         * 4 samples a launch (the 4096^2 frame of config 5) was a third of the frame */
         const uint64_t resident_paths = getenv("DRT_RESIDENT_PATHS_M") ? (uint64_t)std::max(1, atoi(getenv("DRT_RESIDENT_PATHS_M"))) << 20 : (256ull << 20);
         const uint64_t by_paths = std::max<uint64_t>(1, std::min<uint64_t>(DRT_DEFAULT_MAX_BATCH, resident_paths / npx));
         batch = (uint32_t)std::max<uint64_t>(by_paths, 16);

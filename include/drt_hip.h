@@ -167,7 +167,7 @@ typedef struct drt_params
     int32_t  device;       /* HIP device ordinal */
     uint32_t batch_spp;    /* samples traced per launch pair. 0 = sized for a job of `spp` samples (about 32 launch pairs, or as many samples
                               as about 16 GB of vertex records hold, whichever is more); DRT_BATCH_RESIDENT = sized for a context kept across
-                              many frames (64 M paths per launch, at least 16 samples per pixel, as memory allows) */
+                              many frames (up to 256 M paths per launch, at least 16 samples per pixel, as memory allows) */
     uint32_t flags;        /* DRT_FLAG_* */
 } drt_params;
 
