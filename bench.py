@@ -48,16 +48,49 @@ def load_workload_scene(scene, W, H):
     return pydrt.load_scene(os.path.join(REPO, "scenes", scene), W, H)
 
 
+def _code_only(text):
+    """C / C++ source without its comments and with runs of white space collapsed: what the compiler sees. String and character
+    literals are kept as they are (a "//" inside one is not a comment)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            while j > 0 and text[j - 1] == "\\":  # a line comment continued by a backslash
+                j = text.find("\n", j + 1)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            if out and out[-1] != " ":
+                out.append(" ")
+            i = n if j < 0 else j + 2
+        elif c.isspace():
+            if out and out[-1] != " ":
+                out.append(" ")
+            i += 1
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out).strip()
+
+
 def csrc_sha():
-    """sha256 over the kernel sources: stamps profiles/roofline*.json (tools/roofline_from_profiles.py), so that per-path counters
-    taken from an OLDER build of the kernels are not multiplied by this build's timings."""
+    """sha256 over the kernel sources AS CODE (comments and white space taken out: rewording a comment is not another build): stamps
+    profiles/roofline*.json (tools/roofline_from_profiles.py), so that per-path counters taken from an OLDER build of the kernels are
+    not multiplied by this build's timings."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(REPO, "daily-ray-trace_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".h", ".hip")):
             h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+            h.update(_code_only(open(os.path.join(d, name), encoding="utf-8", errors="replace").read()).encode())
     return h.hexdigest()[:16]
 
 

@@ -23,7 +23,7 @@ def test_byte_model_reproduces_the_surveys_figures(v_int, v_shade, kb):
 def test_kernel_source_stamp_follows_the_sources(tmp_path, monkeypatch):
     a = bench.csrc_sha()
     assert a == bench.csrc_sha() and len(a) == 16
-    # another tree with one byte more in one kernel source: another stamp
+    # another tree with the same sources: the same stamp
     src = os.path.join(REPO, "daily-ray-trace_amd", "csrc")
     dst = tmp_path / "daily-ray-trace_amd" / "csrc"
     dst.mkdir(parents=True)
@@ -31,9 +31,18 @@ def test_kernel_source_stamp_follows_the_sources(tmp_path, monkeypatch):
         (dst / name).write_bytes(open(os.path.join(src, name), "rb").read())
     monkeypatch.setattr(bench, "REPO", str(tmp_path))
     assert bench.csrc_sha() == a
+    # a reworded comment or another line break is not another build ...
     with open(dst / "drt_device.h", "ab") as f:
-        f.write(b"\n")
-    assert bench.csrc_sha() != a
+        f.write(b"\n/* a remark with a \" and a ' in it */  // and one more\n")
+    assert bench.csrc_sha() == a
+    # ... a changed token is, also inside a string literal
+    with open(dst / "drt_device.h", "ab") as f:
+        f.write(b"static const char *drt_probe_text = \"// not a comment\";\n")
+    b = bench.csrc_sha()
+    assert b != a
+    text = (dst / "drt_device.h").read_text().replace("// not a comment", "// not a  comment")
+    (dst / "drt_device.h").write_text(text)
+    assert bench.csrc_sha() not in (a, b)
 
 
 def _roofline(workload, profile_name="roofline.json"):
