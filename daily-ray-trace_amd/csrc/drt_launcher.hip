@@ -1239,6 +1239,18 @@ static int enqueue_pair(drt_context *ctx, uint32_t first_sample, uint32_t n, uin
     if (const char *e = getenv("DRT_DEBUG_TAIL_PHASE_A_OFF")) sp.tail_staged = (uint32_t)atoi(e) ? 1u : sp.tail_staged;
     sp.cmf_rw = ctx->cmf_rw; sp.cmf_x = ctx->cmf_x; sp.cmf_y = ctx->cmf_y; sp.cmf_z = ctx->cmf_z;
     sp.chunk = ctx->tail_count ? 64u / ctx->tail_count : SHADE_PIXEL_CHUNK;
+    if (ctx->tail_count && !sp.tail_staged)
+    {
+        /* A group's tail-pass item is the longest item of the queue: the replay of every path of its pixels that the trace kernel did
+         * not carry, 1-4 ms where glass fills them -- the floor under a small launch. Its lane groups take PATHS, not pixels, so a group
+         * of fewer pixels is replayed by the same 64 / R lane groups in that much less time, and only the short film phase runs with
+         * lanes to spare. Worth it where a wave gets fewer than two such items (64 rows x 1024 px x 256 spp: shade 6.8 -> 6.1 ms with
+         * half the pixels per group, 8 rows: 3.9 -> 1.6 with a quarter); the whole frame loses (80.2 -> 82.7: more, emptier film phases). */
+        const uint64_t tail_items = (n_pix + sp.chunk - 1) / sp.chunk, waves_ = (uint64_t)ctx->shade_grid_cap * SHADE_WAVES;
+        if (2 * tail_items < waves_) sp.chunk = std::max(1u, sp.chunk / 4);
+        else if (tail_items < 2 * waves_) sp.chunk = std::max(1u, sp.chunk / 2);
+    }
+    if (const char *e = getenv("DRT_SHADE_CHUNK")) sp.chunk = std::max(1u, std::min(ctx->tail_count ? 64u / ctx->tail_count : SHADE_PIXEL_CHUNK, (uint32_t)atoi(e))); /* tuning knob */
     uint64_t groups = (n_pix + sp.chunk - 1) / sp.chunk;
     const bool inline_tail = ctx->tail_count != 0;
     /* work items: a group's main pass in pieces of sub_pixels pixels (+ its tail pass as an item of its own) when the
