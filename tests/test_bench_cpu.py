@@ -75,8 +75,14 @@ def test_roofline_object_with_fresh_stale_and_missing_profiles(tmp_path, monkeyp
     assert r["frac"] is None and "no committed PMC profile" in r["note"]
 
 
-def test_committed_profiles_name_their_workloads():
-    """Each profiles/roofline*.json is keyed by the workload string bench.py builds for --workload configN."""
+def test_committed_profiles_name_their_workloads_and_belong_to_this_build():
+    """Each profiles/roofline*.json is keyed by the workload string bench.py builds for --workload configN, and was taken from the
+    kernel sources as they are NOW: a change to csrc/ (other than to its comments) means the rocprofv3 passes are run again
+    (tools/r03_refresh_profiles.sh on the GPU box, tools/r03_install_profiles.sh here) before it is committed -- otherwise the bench line
+    would carry no roofline fraction (it refuses counters of another build)."""
     for name in ("roofline.json", "roofline_config3.json", "roofline_config4.json", "roofline_config5.json"):
         pj = json.load(open(os.path.join(REPO, "profiles", name)))
         assert pj["workload"] and len(pj["csrc_sha"]) == 16 and {"shade"} <= set(pj["kernels"])
+        assert pj["csrc_sha"] == bench.csrc_sha(), "%s was taken from other kernel sources: refresh the profiles" % name
+    line = json.load(open(os.path.join(REPO, "profiles", "r03_bench_line.json")))
+    assert line["roofline"]["frac"] is not None and "stale_profile" not in line["roofline"]
