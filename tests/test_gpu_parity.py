@@ -1048,6 +1048,19 @@ def test_shade_kernel_without_the_fresnel_code_changes_no_bit(scene, size, spp, 
     monkeypatch.delenv("DRT_TRACE_TAIL", raising=False)
 
 
+@pytest.mark.parametrize("spp,first_sample", [(9000, 0), (300, 4294967295 - 300), (5000, 70000)])
+def test_many_samples_and_sample_numbers_up_to_2_to_the_32(spp, first_sample):
+    """A tile whose call takes thousands of samples per pixel (dozens of kernel pairs of equal size), sample numbers beyond 16 bits and
+    up to 2^32 - 1 (the running mean divides by them), a seed near 2^64 (the path key wraps as the reference's u64 does): every hit
+    index, the draw counts and the film equal the oracle's."""
+    bundle = pydrt.load_scene(cases.scene_path("cornell_plane_light.scn"), 64, 64)
+    p = pydrt.make_params(64, 64, spp=spp, first_sample=first_sample, max_depth=8, seed=0xFFFFFFFFFFFFFF00, x0=30, y0=40, tile_w=4, tile_h=3)
+    film, hits, xyz, st = _render_all(bundle, p)
+    opx, oav, ova, ohits, ost = O.oracle_render_tile(bundle, p, want_hits=True, math_mode=O.MATH_DEVICE, num_threads=16)
+    assert np.array_equal(hits, ohits) and _counts(st) == _counts(ost)
+    assert cases.rel_err(film[0], opx) <= FILM_TOL and cases.rel_err(film[1], oav) <= FILM_TOL and cases.rel_err(film[2], ova) <= FILM_TOL
+
+
 def test_hundred_thousand_spheres_through_the_hierarchy():
     """Ten times BASELINE config 5's scene (the same generator, 100 000 spheres; 400 000 were checked by hand the same way): the host
     builds the hierarchy (20 levels of the 32 the traversal stacks hold), the two BVH kernels walk it, and every hit index, the draw
