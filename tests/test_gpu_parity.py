@@ -1061,6 +1061,22 @@ def test_many_samples_and_sample_numbers_up_to_2_to_the_32(spp, first_sample):
     assert cases.rel_err(film[0], opx) <= FILM_TOL and cases.rel_err(film[1], oav) <= FILM_TOL and cases.rel_err(film[2], ova) <= FILM_TOL
 
 
+@pytest.mark.parametrize("depth", [1, 300, 524])
+def test_depth_limits_one_vertex_and_the_deepest_the_records_hold(depth):
+    """max_depth 1 (a camera ray, its light sample, nothing else) and the deepest path a record table block can describe (524
+    vertices: three blocks in the header, 128 in the table, four vertices each): hit indices, draw counts and film against the
+    oracle; one more is refused by drt_create with the reason."""
+    bundle = pydrt.load_scene(cases.scene_path("cornell_large_box.scn"), 16, 16)
+    p = pydrt.make_params(16, 16, spp=3, max_depth=depth, seed=5)
+    film, hits, xyz, st = _render_all(bundle, p)
+    opx, oav, ova, ohits, ost = O.oracle_render_tile(bundle, p, want_hits=True, math_mode=O.MATH_DEVICE, num_threads=8)
+    assert np.array_equal(hits, ohits) and _counts(st) == _counts(ost)
+    assert cases.rel_err(film[0], opx) <= FILM_TOL and cases.rel_err(film[2], ova) <= FILM_TOL
+    if depth == 524:
+        with pytest.raises(RuntimeError, match="max_depth 525"):
+            pydrt.Renderer(bundle, pydrt.make_params(16, 16, spp=1, max_depth=525, seed=5))
+
+
 def test_hundred_thousand_spheres_through_the_hierarchy():
     """Ten times BASELINE config 5's scene (the same generator, 100 000 spheres; 400 000 were checked by hand the same way): the host
     builds the hierarchy (20 levels of the 32 the traversal stacks hold), the two BVH kernels walk it, and every hit index, the draw
