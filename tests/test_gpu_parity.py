@@ -1077,6 +1077,26 @@ def test_depth_limits_one_vertex_and_the_deepest_the_records_hold(depth):
             pydrt.Renderer(bundle, pydrt.make_params(16, 16, spp=1, max_depth=525, seed=5))
 
 
+@pytest.mark.parametrize("n_extra", [28, 70, 200])
+def test_forty_to_two_hundred_lights(n_extra):
+    """test_many_lights.scn with 28, 70 and 200 more plane lights: every vertex samples every light (src/daily_ray_trace.c:286), so a
+    vertex record grows to 1, 2 and 8 KB (record blocks of 8, 16 and 64 KB), far beyond what the shade kernel prefetches; with 200
+    the scene has 218 surfaces and goes through the hierarchy. Hit indices, draw and shadow-ray counts and the film against the oracle."""
+    text = open(cases.scene_path("test_many_lights.scn")).read()
+    for k in range(n_extra):
+        x, z = -2.8 + 5.6 * (k % 20) / 20.0, -2.5 + 0.25 * (k // 20)
+        text += "\nSurface\nname extra%d\ntype plane\nposition %.3f, 2.8, %.3f\npointu %.3f, 2.8, %.3f\npointv %.3f, 2.8, %.3f\nmaterial light%d\n" % (
+            k, x, z, x + 0.1, z, x, z - 0.1, k % 3)
+    bundle = pydrt.load_scene_text(text, 16, 16)
+    p = pydrt.make_params(16, 16, spp=2, max_depth=5, seed=4)
+    film, hits, xyz, st = _render_all(bundle, p)
+    opx, oav, ova, ohits, ost = O.oracle_render_tile(bundle, p, want_hits=True, math_mode=O.MATH_DEVICE, num_threads=16)
+    assert bool(st.path_flags & pydrt.PATH_BVH) == (n_extra == 200)
+    assert np.array_equal(hits, ohits) and _counts(st) == _counts(ost)
+    assert cases.rel_err(film[0], opx) <= FILM_TOL and cases.rel_err(film[1], oav) <= FILM_TOL and cases.rel_err(film[2], ova) <= FILM_TOL
+    assert cases.xyz_rel_err(xyz, O.oracle_film_to_xyz(bundle, opx)) <= XYZ_TOL
+
+
 def test_hundred_thousand_spheres_through_the_hierarchy():
     """Ten times BASELINE config 5's scene (the same generator, 100 000 spheres; 400 000 were checked by hand the same way): the host
     builds the hierarchy (20 levels of the 32 the traversal stacks hold), the two BVH kernels walk it, and every hit index, the draw
