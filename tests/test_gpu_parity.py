@@ -1097,6 +1097,30 @@ def test_forty_to_two_hundred_lights(n_extra):
     assert cases.xyz_rel_err(xyz, O.oracle_film_to_xyz(bundle, opx)) <= XYZ_TOL
 
 
+@pytest.mark.parametrize("n_spheres", [40, 150])
+@pytest.mark.parametrize("mode", ["spectral", "xyz"])
+def test_more_spectra_than_lds_holds(n_spheres, mode):
+    """cornell_plane_light.scn plus 150 materials of their own colours on 40 / 150 small spheres: 328 spectral rows, 181 KB at 69
+    samples, more than the 64 KB the shade kernel stages in LDS -- its instantiation that reads the table from memory
+    (SPDS_IN_LDS = false), never met by another test; with 150 spheres also through the hierarchy. Against the oracle."""
+    text = open(cases.scene_path("cornell_plane_light.scn")).read()
+    for k in range(150):
+        text += "\nMaterial\nname m%d\ndiffuse rgb %.3f, %.3f, %.3f\nglossy rgb %.3f, 0.1, 0.1\nshininess %d.0\nbdsfs bp_diffuse_bdsf, bp_glossy_bdsf\ndir_func cos_weighted_sample_hemisphere\n" % (
+            k, 0.1 + 0.8 * ((k * 7) % 11) / 11.0, 0.1 + 0.8 * ((k * 3) % 13) / 13.0, 0.1 + 0.8 * (k % 17) / 17.0, 0.05 + 0.3 * (k % 5) / 5.0, 10 + k % 90)
+    for k in range(n_spheres):
+        text += "\nSurface\nname s%d\ntype sphere\nposition %.3f, %.3f, %.3f\nradius 0.12\nmaterial m%d\n" % (
+            k, -2.5 + 5.0 * (k % 10) / 9.0, -2.6 + 0.35 * (k // 10), -2.0 + 0.37 * (k % 7), k % 150)
+    bundle = pydrt.load_scene_text(text, 24, 24)
+    assert int(bundle.scene.num_spds) * bundle.S * 8 > 64 * 1024
+    p = pydrt.make_params(24, 24, spp=3, max_depth=6, seed=4, mode=pydrt.MODE_XYZ if mode == "xyz" else pydrt.MODE_SPECTRAL)
+    film, hits, xyz, st = _render_all(bundle, p)
+    opx, oav, ova, ohits, ost = O.oracle_render_tile(bundle, pydrt.make_params(24, 24, spp=3, max_depth=6, seed=4), want_hits=True, math_mode=O.MATH_DEVICE, num_threads=16)
+    assert bool(st.path_flags & pydrt.PATH_BVH) == (n_spheres == 150) and np.array_equal(hits, ohits) and _counts(st) == _counts(ost)
+    if mode == "spectral":
+        assert cases.rel_err(film[0], opx) <= FILM_TOL and cases.rel_err(film[1], oav) <= FILM_TOL and cases.rel_err(film[2], ova) <= FILM_TOL
+    assert cases.xyz_rel_err(xyz, O.oracle_film_to_xyz(bundle, opx)) <= XYZ_TOL
+
+
 def test_hundred_thousand_spheres_through_the_hierarchy():
     """Ten times BASELINE config 5's scene (the same generator, 100 000 spheres; 400 000 were checked by hand the same way): the host
     builds the hierarchy (20 levels of the 32 the traversal stacks hold), the two BVH kernels walk it, and every hit index, the draw
