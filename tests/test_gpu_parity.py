@@ -1121,6 +1121,19 @@ def test_more_spectra_than_lds_holds(n_spheres, mode):
     assert cases.xyz_rel_err(xyz, O.oracle_film_to_xyz(bundle, opx)) <= XYZ_TOL
 
 
+@pytest.mark.parametrize("W,H,tile", [(200000, 3, dict(x0=99950, y0=1, tile_w=100, tile_h=2)), (5, 3000000, dict(x0=1, y0=1499995, tile_w=3, tile_h=10)),
+                                      (70000, 70000, dict(x0=69990, y0=69995, tile_w=10, tile_h=5)), (70000, 70000, dict(x0=35000, y0=34990, tile_w=12, tile_h=4, row_stride=3))])
+def test_tiles_of_images_of_extreme_size(W, H, tile):
+    """Tiles of frames that are 200 000 pixels wide, 3 000 000 high, and 70 000 x 70 000 (4.9 G pixels: pixel numbers and path keys
+    beyond 32 bits), at the far corner and in the middle: hit indices, draw counts and film against the oracle."""
+    bundle = pydrt.load_scene(cases.scene_path("cornell_plane_light.scn"), W, H)
+    p = pydrt.make_params(W, H, spp=3, max_depth=6, seed=2, **tile)
+    film, hits, xyz, st = _render_all(bundle, p)
+    opx, oav, ova, ohits, ost = O.oracle_render_tile(bundle, p, want_hits=True, math_mode=O.MATH_DEVICE, num_threads=8)
+    assert np.array_equal(hits, ohits) and _counts(st) == _counts(ost)
+    assert cases.rel_err(film[0], opx) <= FILM_TOL and cases.rel_err(film[2], ova) <= FILM_TOL
+
+
 def test_hundred_thousand_spheres_through_the_hierarchy():
     """Ten times BASELINE config 5's scene (the same generator, 100 000 spheres; 400 000 were checked by hand the same way): the host
     builds the hierarchy (20 levels of the 32 the traversal stacks hold), the two BVH kernels walk it, and every hit index, the draw
