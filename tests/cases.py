@@ -67,3 +67,36 @@ def rel_err(a, b):
 def xyz_rel_err(a, b, floor=1e-9):
     """per-pixel, per-channel relative error of XYZ (the metric BASELINE.json names), with an absolute floor."""
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+
+
+def _surface(name, kind, body, material):
+    return "\nSurface\nname %s\ntype %s\n%s\nmaterial %s\n" % (name, kind, body, material)
+
+
+def degenerate_scenes():
+    """cornell_plane_light.scn with geometry and materials a loader would rather not see, as .scn text by name: what the reference's
+    arithmetic makes of them (ties by surface order, NaN from a 0 / 0, a sphere of radius 0 ...) is the expected output."""
+    base = open(scene_path("cornell_plane_light.scn")).read()
+    odd = ("\nMaterial\nname odd1\ndiffuse rgb 0.5, 0.5, 0.5\nglossy rgb 0.3, 0.3, 0.3\nshininess 2.5\nbdsfs bp_diffuse_bdsf, bp_glossy_bdsf\n"
+           "dir_func cos_weighted_sample_hemisphere\n\nMaterial\nname odd2\ndiffuse rgb 0.5, 0.5, 0.5\nglossy rgb 0.3, 0.3, 0.3\nshininess 1000000.0\n"
+           "bdsfs bp_diffuse_bdsf, bp_glossy_bdsf\ndir_func uniform_sample_hemisphere\n")
+    return {
+        "coincident_surfaces": base + _surface("floor2", "plane", "position -3.0, -3.0, -3.0\npointu 3.0, -3.0, -3.0\npointv -3.0, -3.0, 3.0", "red_plastic")
+                                    + _surface("gold2", "sphere", "position 2.0, -2.0, -0.5\nradius 0.75", "dielectric"),
+        "zero_and_negative_radius": base + _surface("z", "sphere", "position 0.0, 0.0, 0.0\nradius 0.0", "red_plastic")
+                                         + _surface("n", "sphere", "position 0.5, -1.0, 0.5\nradius -0.6", "green_plastic"),
+        "plane_with_parallel_edges": base + _surface("deg", "plane", "position -1.0, -1.0, 0.0\npointu 0.0, -1.0, 0.0\npointv 1.0, -1.0, 0.0", "red_plastic"),
+        "plane_with_a_zero_edge": base + _surface("deg0", "plane", "position -1.0, -1.0, 0.0\npointu -1.0, -1.0, 0.0\npointv 1.0, -1.0, 0.5", "red_plastic"),
+        "huge_and_tiny_spheres": base + _surface("far", "sphere", "position 0.0, 0.0, -900000.0\nradius 899997.5", "green_plastic")
+                                      + _surface("dust", "sphere", "position 0.2, 0.1, 1.0\nradius 0.000001", "red_plastic"),
+        "roughness_0_and_odd_shininess": base.replace("roughness 0.1", "roughness 0.0").replace("shininess 16.0", "shininess 0.0") + odd
+                                         + _surface("o1", "sphere", "position 0.0, -2.0, 1.0\nradius 0.5", "odd1") + _surface("o2", "sphere", "position 1.0, -2.3, 1.5\nradius 0.5", "odd2"),
+        "camera_inside_the_glass_ball": base.replace("position 0.0, 0.0, 8.0", "position -1.5, -1.8, 2.2"),
+        # lights: a point light ON a wall and one inside the glass ball, a sphere light that swallows the gold ball, a plane light of no area
+        "awkward_lights": base + "\nMaterial\nname extra_light\nemission constant 0.7\nis_black_body true\n"
+                               + _surface("on_wall", "point", "position -3.0, 0.5, 0.5", "extra_light") + _surface("in_glass", "point", "position -1.5, -1.8, 2.0", "extra_light")
+                               + _surface("big_bulb", "sphere", "position 2.0, -2.0, -0.5\nradius 0.9", "extra_light")
+                               + _surface("no_area", "plane", "position 0.0, 2.5, 0.0\npointu 0.0, 2.5, 0.0\npointv 0.5, 2.5, 0.5", "extra_light"),
+        # a thin lens as wide as the room, focused on the back wall
+        "enormous_aperture": base.replace("aperture 0.0", "aperture 2.5"),
+    }

@@ -1134,6 +1134,24 @@ def test_tiles_of_images_of_extreme_size(W, H, tile):
     assert cases.rel_err(film[0], opx) <= FILM_TOL and cases.rel_err(film[2], ova) <= FILM_TOL
 
 
+@pytest.mark.parametrize("name", list(cases.degenerate_scenes()))
+@pytest.mark.parametrize("through_the_hierarchy", [False, True])
+def test_degenerate_geometry_and_materials(name, through_the_hierarchy, monkeypatch):
+    """tests/cases.py degenerate_scenes(): coincident surfaces (ties go to the lower index), spheres of radius 0 and -0.6, planes whose
+    edges are parallel or of length 0, a sphere of radius 900 km next to one of a micron, roughness 0 (a 0 / 0 in ggx: NaN films,
+    compared NaN for NaN) with shininess 0, 2.5 and 10^6, the camera inside the glass ball -- by the flat scan and (DRT_FORCE_BVH) through
+    the hierarchy: hit indices, draw counts and film against the oracle."""
+    if through_the_hierarchy:
+        monkeypatch.setenv("DRT_FORCE_BVH", "1")
+    bundle = pydrt.load_scene_text(cases.degenerate_scenes()[name], 24, 24)
+    p = pydrt.make_params(24, 24, spp=4, max_depth=8, seed=3)
+    film, hits, xyz, st = _render_all(bundle, p)
+    opx, oav, ova, ohits, ost = O.oracle_render_tile(bundle, p, want_hits=True, math_mode=O.MATH_DEVICE, num_threads=16)
+    assert bool(st.path_flags & pydrt.PATH_BVH) == through_the_hierarchy
+    assert np.array_equal(hits, ohits) and _counts(st) == _counts(ost)
+    assert fuzz_scenes.same(film[0], opx, FILM_TOL) and fuzz_scenes.same(film[1], oav, FILM_TOL) and fuzz_scenes.same(film[2], ova, FILM_TOL)
+
+
 def test_hundred_thousand_spheres_through_the_hierarchy():
     """Ten times BASELINE config 5's scene (the same generator, 100 000 spheres; 400 000 were checked by hand the same way): the host
     builds the hierarchy (20 levels of the 32 the traversal stacks hold), the two BVH kernels walk it, and every hit index, the draw

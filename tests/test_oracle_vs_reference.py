@@ -81,6 +81,21 @@ def test_random_scenes_bit_identical(seed):
         assert fuzz_scenes.same(replay, real) and np.array_equal(hits, ohits)
 
 
+@pytest.mark.parametrize("name", list(cases.degenerate_scenes()))
+def test_degenerate_geometry_and_materials_bit_identical(name):
+    """tests/cases.py degenerate_scenes() -- coincident surfaces, radius 0 and negative, planes with parallel or zero edges, a 900 km
+    sphere, roughness 0 (NaN films), the camera inside glass: whatever the reference's arithmetic makes of them, the oracle in reference
+    arithmetic makes the same, film and hit indices, NaN for NaN."""
+    bundle = pydrt.load_scene_text(cases.degenerate_scenes()[name], 24, 24)
+    params = pydrt.make_params(24, 24, spp=4, max_depth=8, seed=3)
+    rp, ra, rv = O.ref_render_tile(bundle, params)
+    op, oa, ov, ohits, _ = O.oracle_render_tile(bundle, params, want_hits=True, math_mode=O.MATH_REFERENCE)
+    assert fuzz_scenes.same(op, rp) and fuzz_scenes.same(oa, ra) and fuzz_scenes.same(ov, rv)
+    if bundle.camera.aperture_radius == 0.0:  # the harness's hit log replays pinhole paths only (oracle/ref_harness.c)
+        hits, replay, real = O.ref_trace_hits(bundle, params)
+        assert fuzz_scenes.same(replay, real) and np.array_equal(hits, ohits)
+
+
 @pytest.mark.parametrize("S", list(fuzz_scenes.FUZZ_GRIDS))
 def test_random_scenes_on_other_wavelength_grids_bit_identical(S):
     """The same comparison on grids from 2 to 256 wavelengths (incl. grids that end below the 630 nm the dielectric
