@@ -570,6 +570,38 @@ def test_one_shot_render_tile_accumulates_into_host_buffers():
     assert cases.rel_err(zx, o4[0]) <= FILM_TOL and cases.rel_err(zv, o4[2]) <= FILM_TOL
 
 
+@pytest.mark.parametrize("scene", ["first_scene.scn", "cornell_plane_light.scn"])
+@pytest.mark.parametrize("dark_skip", ["0", "1"])
+def test_accumulating_into_a_film_that_holds_minus_zero_nan_infinities_and_subnormals(scene, dark_skip, monkeypatch):
+    """render_image adds to the caller's buffers (src/daily_ray_trace.c:732-743); here they arrive with -0, NaN, +-inf, subnormal and huge
+    values sprinkled over sum, mean and variance, and samples 7..11 are added: finite values within the film tolerance, NaN and
+    infinities in the same places, and every zero with the oracle's sign -- with the shade kernel's shortcut for dark pixels (which must
+    see that a pixel holding -0 is NOT all +0) and without it."""
+    monkeypatch.setenv("DRT_DARK_SKIP", dark_skip)
+    rng = np.random.default_rng(3)
+    bundle = pydrt.load_scene(cases.scene_path(scene), 24, 24)
+    S, n = bundle.S, 24 * 24
+    p = pydrt.make_params(24, 24, spp=5, max_depth=6, seed=2, first_sample=7)
+    specials = np.array([-0.0, np.nan, np.inf, -np.inf, 5e-324, -1e-310, 1e300, -3.5, 0.25])
+    px, av, va = np.zeros((n, S + 1)), np.zeros((n, S)), np.zeros((n, S))
+    for a in (px, av, va):
+        idx = rng.integers(0, a.size, a.size // 6)
+        a.reshape(-1)[idx] = specials[rng.integers(0, specials.size, idx.size)]
+    px[:, S] = 7.0
+    ox, oa, ov = px.copy(), av.copy(), va.copy()
+    f64p = C.POINTER(C.c_double)
+    st, ost = pydrt.Stats(), pydrt.Stats()
+    assert pydrt.hip_lib().drt_render_tile(C.byref(bundle.scene), C.byref(bundle.camera), C.byref(p), px.ctypes.data_as(f64p), av.ctypes.data_as(f64p),
+                                           va.ctypes.data_as(f64p), C.byref(st)) == 0
+    O.set_math_mode(O.MATH_DEVICE)
+    assert O.oracle_lib().drt_oracle_render_tile(C.byref(bundle.scene), C.byref(bundle.camera), C.byref(p), ox.ctypes.data_as(f64p), oa.ctypes.data_as(f64p),
+                                                 ov.ctypes.data_as(f64p), None, C.byref(ost), 8) == 0
+    for got, want in ((px, ox), (av, oa), (va, ov)):
+        assert fuzz_scenes.same(got, want, FILM_TOL)
+        assert np.array_equal(np.signbit(got[got == 0]), np.signbit(want[want == 0]))
+    assert np.isnan(ox).sum() > 100 and _counts(st) == _counts(ost)
+
+
 def test_errors_are_reported_not_swallowed():
     bundle, params = cases.load_case("plane_light_16")
     L = pydrt.hip_lib()
